@@ -1,0 +1,70 @@
+/*
+ * mvn_engine_api.h -- C ABI of the device-resident engine underneath multiviewnative.h.
+ *
+ * Not part of the reference's interface: these entry points expose what the reference keeps
+ * internal (gpu::plan_store, inc/plan_store.cuh:20-216; the all-on-device RL driver,
+ * src/gpu_deconvolve_methods.cuh:345-562; inplace_3d_transform_on_device,
+ * inc/cufft_utils.cuh:41-75) so that benches, the multi-GPU launcher and the parity tests can
+ * keep data resident in HBM between steps.  Plain pointers and sizes only.  Every function
+ * returns 0 on success and a negative value on failure (message via mvn_last_error()).
+ */
+#ifndef MVN_ENGINE_API_H
+#define MVN_ENGINE_API_H
+
+#include <stddef.h>
+
+#include "multiviewnative.h"
+
+typedef struct mvn_engine mvn_engine; /* opaque */
+
+MVN_API const char* mvn_last_error(void);
+MVN_API const char* mvn_backend_name(void);
+
+/* ---- plan_store (inc/plan_store.cuh: get()/add/has_key/empty/size/clear) ---------------- */
+MVN_API int mvn_plan_store_add(int device, const int dims[3]);
+MVN_API int mvn_plan_store_has_key(int device, const int dims[3]); /* 1 / 0 */
+MVN_API int mvn_plan_store_size(void);
+MVN_API int mvn_plan_store_empty(void);
+MVN_API int mvn_plan_store_clear(void);
+/* layout facts of a shape: {h, C, RP, even, rows_T, ax1_T, ax0_T, n_stages(d2 axis)} */
+MVN_API int mvn_plan_describe(int device, const int dims[3], int out[8]);
+
+/* ---- whole 3-D transforms on host buffers (test/bench utility) --------------------------
+ * real:  dense [d0][d1][d2] floats.  spec: [d0][d1][d2/2+1] complex64 in the FFTW/cuFFT
+ * in-place order (inc/image_stack_utils.h:24-42).  Un-normalised both ways. */
+MVN_API int mvn_fft3_r2c(int device, const int dims[3], const float* real, float* spec);
+MVN_API int mvn_fft3_c2r(int device, const int dims[3], const float* spec, float* real);
+/* times `reps` forward (direction 0) or backward (1) transforms of a resident volume with
+ * stream events; returns average milliseconds per transform in *ms */
+MVN_API int mvn_fft3_time(int device, const int dims[3], int direction, int reps, float* ms);
+
+/* ---- resident RL engine ----------------------------------------------------------------- */
+MVN_API int mvn_engine_create(int device, const int dims[3], int num_views, mvn_engine** out);
+MVN_API int mvn_engine_destroy(mvn_engine* e);
+MVN_API int mvn_engine_set_view(mvn_engine* e, int v, const float* image, const float* weights,
+                                const float* kernel1, const int k1dims[3], const float* kernel2,
+                                const int k2dims[3]);
+MVN_API int mvn_engine_set_psi(mvn_engine* e, const float* psi);
+MVN_API int mvn_engine_get_psi(mvn_engine* e, float* psi);
+/* enqueue `iterations` sequential (Gauss-Seidel) sweeps over the views */
+MVN_API int mvn_engine_iterate(mvn_engine* e, int iterations, double lambda, float min_value);
+/* simultaneous (Jacobi) mode, one step: delta = sum_v w_v (next_v - psi) over this engine's
+ * views; the caller all-reduces the delta buffer across ranks, then applies it */
+MVN_API int mvn_engine_compute_delta(mvn_engine* e, double lambda, float min_value);
+MVN_API int mvn_engine_apply_delta(mvn_engine* e);
+MVN_API int mvn_engine_delta_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);
+MVN_API int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);
+MVN_API int mvn_engine_stream(mvn_engine* e, void** hip_stream);
+MVN_API int mvn_engine_sync(mvn_engine* e);
+/* wall time of `iterations` sweeps measured with events on the engine stream */
+MVN_API int mvn_engine_time_iterate(mvn_engine* e, int iterations, double lambda,
+                                    float min_value, float* ms);
+/* per-kernel event timing: enable, run, then read totals.  kind indexes mvn_kernel_kind_name */
+MVN_API int mvn_engine_profile(mvn_engine* e, int enable);
+MVN_API int mvn_engine_profile_read(mvn_engine* e, int kind, double* total_ms, long* launches);
+MVN_API int mvn_kernel_kind_count(void);
+MVN_API const char* mvn_kernel_kind_name(int kind);
+/* algorithmic bytes B = 4*d0*d1*2(d2/2+1) of the engine's shape */
+MVN_API size_t mvn_engine_B(mvn_engine* e);
+
+#endif

@@ -1,0 +1,596 @@
+// mvn_abi.cpp -- extern "C" boundary: the reference ABI (include/multiviewnative.h) and the
+// engine ABI (include/mvn_engine_api.h).  Nothing escapes as an exception; failures leave the
+// caller's in/out buffers untouched, print one diagnostic to stderr and never terminate the
+// host process (SURVEY.md 8b "Errors").
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mvn_engine_api.h"
+#include "mvn_engine.hpp"
+
+using namespace mvn;
+
+struct mvn_engine {
+  std::unique_ptr<Engine> impl;
+};
+
+static thread_local std::string g_last_error;
+
+static bool trace_on() {
+  const char* t = std::getenv("MVN_TRACE");
+  return t && *t && std::strcmp(t, "0") != 0;
+}
+
+template <typename F>
+static int guarded(const char* where, F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = std::string(where) + ": " + e.what();
+  } catch (...) {
+    g_last_error = std::string(where) + ": unknown failure";
+  }
+  std::fprintf(stderr, "[libmultiviewnative] %s\n", g_last_error.c_str());
+  return -1;
+}
+
+// one ABI call at a time per device (the reference is not re-entrant, SURVEY.md 8b "Threading")
+static std::mutex& device_mutex(int device) {
+  static std::mutex table_mu;
+  static std::map<int, std::unique_ptr<std::mutex>> table;
+  std::lock_guard<std::mutex> lk(table_mu);
+  auto& m = table[device];
+  if (!m) m.reset(new std::mutex());
+  return *m;
+}
+
+static int pick_device(int device) {
+  if (device < 0) device = selectDeviceWithHighestComputeCapability();
+  const int n = be::device_count();
+  if (device < 0 || device >= n)
+    throw std::runtime_error("no usable GPU (requested device " + std::to_string(device) + ", " +
+                             std::to_string(n) + " present)");
+  return device;
+}
+
+static shape_t to_shape(const int* d) {
+  shape_t s = {{d[0], d[1], d[2]}};
+  return s;
+}
+
+extern "C" {
+
+const char* mvn_last_error(void) { return g_last_error.c_str(); }
+const char* mvn_backend_name(void) { return be::backend_name(); }
+
+// ---------------------------------------------------------------------------------------------
+// device queries (inc/cuda_helpers.cuh:70-136)
+// ---------------------------------------------------------------------------------------------
+int getNumDevicesCUDA(void) {
+  int n = 0;
+  guarded("getNumDevicesCUDA", [&] { n = be::device_count(); });
+  return n;
+}
+
+int getCUDAcomputeCapabilityMajorVersion(int devCUDA) {
+  int major = 0, minor = 0;
+  guarded("getCUDAcomputeCapabilityMajorVersion", [&] { be::device_arch(devCUDA, &major, &minor); });
+  return major;
+}
+
+int getCUDAcomputeCapabilityMinorVersion(int devCUDA) {
+  int major = 0, minor = 0;
+  guarded("getCUDAcomputeCapabilityMinorVersion", [&] { be::device_arch(devCUDA, &major, &minor); });
+  return minor;
+}
+
+void getNameDeviceCUDA(int devCUDA, char* name) {
+  if (!name) return;
+  std::memset(name, 0, 256);
+  guarded("getNameDeviceCUDA", [&] { be::device_name(devCUDA, name); });
+}
+
+long long int getMemDeviceCUDA(int devCUDA) {
+  long long v = 0;
+  guarded("getMemDeviceCUDA", [&] { v = be::device_total_mem(devCUDA); });
+  return v;
+}
+
+int selectDeviceWithHighestComputeCapability(void) {
+  int value = -1;
+  guarded("selectDeviceWithHighestComputeCapability", [&] {
+    const int n = be::device_count();
+    int best = 0;
+    for (int d = 0; d < n; ++d) {  // first device with the highest 10*major+minor wins
+      int major = 0, minor = 0;
+      be::device_arch(d, &major, &minor);
+      const int meta = 10 * major + minor;
+      if (meta > best || value < 0) {
+        best = meta;
+        value = d;
+      }
+    }
+  });
+  return value;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference hot path
+// ---------------------------------------------------------------------------------------------
+void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) {
+  guarded("inplace_gpu_deconvolve", [&] {
+    if (!psi || !input.data_) throw std::invalid_argument("null psi or workspace");
+    const int V = input.num_views_;
+    if (V == 0 || input.num_iterations_ <= 0) return;  // 0 iterations returns psi unchanged
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    const shape_t dims = to_shape(input.data_[0].image_dims_);
+    for (int v = 0; v < V; ++v) {
+      const view_data& d = input.data_[v];
+      if (!d.image_ || !d.kernel1_ || !d.kernel2_ || !d.weights_ || !d.image_dims_ ||
+          !d.kernel1_dims_ || !d.kernel2_dims_)
+        throw std::invalid_argument("view " + std::to_string(v) + " has null members");
+      if (to_shape(d.image_dims_) != dims)
+        throw std::invalid_argument("all views must share image_dims_ (view " + std::to_string(v) + ")");
+      if (d.weights_dims_ && to_shape(d.weights_dims_) != dims)
+        throw std::invalid_argument("weights_dims_ must equal image_dims_ (view " + std::to_string(v) + ")");
+    }
+    // memory heuristic of src/multiviewnative.cu:94-119, restated for the resident layout:
+    // 4 volumes per view (view, weights, two spectra) + psi + work (+ slack)
+    be::set_device(dev);
+    Layout L(dims[0], dims[1], dims[2]);
+    const double need = (4.0 * V + 2.0) * (double)L.B() * 1.02;
+    size_t free_b = 0, total_b = 0;
+    be::device_mem_info(&free_b, &total_b);
+    if (trace_on())
+      std::printf("[lmvn::inplace_gpu_deconvolve] FFT: %.1f MB (all-on-device), available on GPU: %.1f MB ... %s\n",
+                  need / 1048576.0, free_b / 1048576.0, need < free_b ? "all on device!" : "does not fit");
+    if (need >= (double)free_b)
+      throw std::runtime_error("FFT: Unable to run on GPU due to memory constraints");
+    Engine eng(dev, dims, V);
+    for (int v = 0; v < V; ++v) {
+      const view_data& d = input.data_[v];
+      eng.set_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+    }
+    eng.set_psi(psi);
+    eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
+    eng.sync();
+    eng.get_psi(psi);
+  });
+}
+
+// single convolution on the engine's kernels; shared by the three convolution entry points
+static void convolve_host(float* im, const int* imDim, const float* kernel, const int* kernelDim,
+                          int device) {
+  if (!im || !imDim || !kernel || !kernelDim) throw std::invalid_argument("null argument");
+  const int dev = pick_device(device);
+  std::lock_guard<std::mutex> lk(device_mutex(dev));
+  be::set_device(dev);
+  std::shared_ptr<Plan3D> plan = PlanStore::get().add(dev, to_shape(imDim));
+  const Layout& L = plan->L;
+  be::stream_t s = be::stream_create();
+  float* vol = nullptr;
+  float* spec = nullptr;
+  cfloat *nyq = nullptr, *snyq = nullptr;
+  float* dk = nullptr;
+  auto cleanup = [&] {
+    be::dfree(vol);
+    be::dfree(spec);
+    be::dfree(nyq);
+    be::dfree(snyq);
+    be::dfree(dk);
+    be::stream_destroy(s);
+  };
+  try {
+    vol = (float*)be::dmalloc(plan->main_bytes());
+    spec = (float*)be::dmalloc(plan->main_bytes());
+    if (plan->nyq_bytes()) {
+      nyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
+      snyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
+    }
+    const size_t kb = sizeof(float) * (size_t)kernelDim[0] * kernelDim[1] * kernelDim[2];
+    dk = (float*)be::dmalloc(kb);
+    be::h2d(dk, kernel, kb, s);
+    be::dzero(vol, plan->main_bytes(), s);
+    be::h2d_2d(vol, (size_t)L.RP * 4, im, (size_t)L.d2 * 4, (size_t)L.d2 * 4, L.rows, s);
+    const float scale = (float)(1.0 / (double)L.logical());
+    plan->psf_spectrum(dk, kernelDim, scale, spec, snyq, s);
+    EpilogueParams e;
+    std::memset(&e, 0, sizeof(e));
+    e.mode = MVN_EPI_STORE;
+    e.scale = 1.f;
+    plan->convolve(vol, (cfloat*)vol, nyq, (const cfloat*)spec, snyq, vol, e, s);
+    be::d2h_2d(im, (size_t)L.d2 * 4, vol, (size_t)L.RP * 4, (size_t)L.d2 * 4, L.rows, s);
+    be::stream_sync(s);
+  } catch (...) {
+    try {
+      be::stream_sync(s);
+    } catch (...) {
+    }
+    cleanup();
+    throw;
+  }
+  cleanup();
+}
+
+void inplace_gpu_convolution(imageType* im, int* imDim, imageType* kernel, int* kernelDim,
+                             int device) {
+  guarded("inplace_gpu_convolution", [&] { convolve_host(im, imDim, kernel, kernelDim, device); });
+}
+
+void convolution3DfftCUDAInPlace(imageType* im, int* imDim, imageType* kernel, int* kernelDim,
+                                 int devCUDA) {
+  guarded("convolution3DfftCUDAInPlace", [&] { convolve_host(im, imDim, kernel, kernelDim, devCUDA); });
+}
+
+void convolution3DfftCUDAInPlace_core(imageType* d_im, int* imDim, imageType* d_kernel,
+                                      int* kernelDim, int devCUDA) {
+  guarded("convolution3DfftCUDAInPlace_core", [&] {
+    if (!d_im || !imDim || !d_kernel || !kernelDim) throw std::invalid_argument("null argument");
+    const int dev = pick_device(devCUDA);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    be::set_device(dev);
+    std::shared_ptr<Plan3D> plan = PlanStore::get().add(dev, to_shape(imDim));
+    const Layout& L = plan->L;
+    be::stream_t s = be::stream_create();
+    float *vol = nullptr, *spec = nullptr;
+    cfloat *nyq = nullptr, *snyq = nullptr;
+    auto cleanup = [&] {
+      if (vol != d_im) be::dfree(vol);
+      be::dfree(spec);
+      be::dfree(nyq);
+      be::dfree(snyq);
+      be::stream_destroy(s);
+    };
+    try {
+      spec = (float*)be::dmalloc(plan->main_bytes());
+      if (plan->nyq_bytes()) {
+        nyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
+        snyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
+      }
+      if (L.RP == L.d2) {
+        vol = d_im;  // even d2: the caller's dense volume already is the engine layout
+      } else {
+        vol = (float*)be::dmalloc(plan->main_bytes());
+        be::dzero(vol, plan->main_bytes(), s);
+        be::d2d_2d(vol, (size_t)L.RP * 4, d_im, (size_t)L.d2 * 4, (size_t)L.d2 * 4, L.rows, s);
+      }
+      const float scale = (float)(1.0 / (double)L.logical());
+      plan->psf_spectrum(d_kernel, kernelDim, scale, spec, snyq, s);
+      EpilogueParams e;
+      std::memset(&e, 0, sizeof(e));
+      e.mode = MVN_EPI_STORE;
+      e.scale = 1.f;
+      plan->convolve(vol, (cfloat*)vol, nyq, (const cfloat*)spec, snyq, vol, e, s);
+      if (vol != d_im)
+        be::d2d_2d(d_im, (size_t)L.d2 * 4, vol, (size_t)L.RP * 4, (size_t)L.d2 * 4, L.rows, s);
+      be::stream_sync(s);
+    } catch (...) {
+      try {
+        be::stream_sync(s);
+      } catch (...) {
+      }
+      cleanup();
+      throw;
+    }
+    cleanup();
+  });
+}
+
+void compute_quotient(imageType* _input, imageType* _output, size_t _size, int _device) {
+  guarded("compute_quotient", [&] {
+    if (!_input || !_output) throw std::invalid_argument("null argument");
+    if (_size == 0) return;
+    const int dev = pick_device(_device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    be::set_device(dev);
+    const size_t bytes = _size * sizeof(float);
+    float* d_in = (float*)be::dmalloc(bytes);
+    float* d_out = nullptr;
+    try {
+      d_out = (float*)be::dmalloc(bytes);
+      be::h2d(d_in, _input, bytes, nullptr);
+      be::h2d(d_out, _output, bytes, nullptr);
+      be::launch_divide(d_in, d_out, _size, nullptr);
+      std::vector<float> tmp(_size);
+      be::d2h(tmp.data(), d_out, bytes, nullptr);
+      be::stream_sync(nullptr);
+      std::memcpy(_output, tmp.data(), bytes);
+    } catch (...) {
+      be::dfree(d_in);
+      be::dfree(d_out);
+      throw;
+    }
+    be::dfree(d_in);
+    be::dfree(d_out);
+  });
+}
+
+void compute_final_values(imageType* _image, imageType* _integral, imageType* _weight,
+                          size_t _size, float _minValue, double _lambda, int _device) {
+  guarded("compute_final_values", [&] {
+    if (!_image || !_integral || !_weight) throw std::invalid_argument("null argument");
+    if (_size == 0) return;
+    const int dev = pick_device(_device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    be::set_device(dev);
+    const size_t bytes = _size * sizeof(float);
+    float *d_psi = nullptr, *d_int = nullptr, *d_w = nullptr;
+    auto cleanup = [&] {
+      be::dfree(d_psi);
+      be::dfree(d_int);
+      be::dfree(d_w);
+    };
+    try {
+      d_psi = (float*)be::dmalloc(bytes);
+      d_int = (float*)be::dmalloc(bytes);
+      d_w = (float*)be::dmalloc(bytes);
+      be::h2d(d_psi, _image, bytes, nullptr);
+      be::h2d(d_int, _integral, bytes, nullptr);
+      be::h2d(d_w, _weight, bytes, nullptr);
+      be::launch_update(d_psi, d_int, d_w, _size, _lambda, _minValue, nullptr);
+      std::vector<float> tmp(_size);
+      be::d2h(tmp.data(), d_psi, bytes, nullptr);
+      be::stream_sync(nullptr);
+      std::memcpy(_image, tmp.data(), bytes);
+    } catch (...) {
+      cleanup();
+      throw;
+    }
+    cleanup();
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan_store
+// ---------------------------------------------------------------------------------------------
+int mvn_plan_store_add(int device, const int dims[3]) {
+  return guarded("mvn_plan_store_add", [&] { PlanStore::get().add(pick_device(device), to_shape(dims)); });
+}
+
+int mvn_plan_store_has_key(int device, const int dims[3]) {
+  int r = 0;
+  int rc = guarded("mvn_plan_store_has_key",
+                   [&] { r = PlanStore::get().has_key(pick_device(device), to_shape(dims)) ? 1 : 0; });
+  return rc < 0 ? rc : r;
+}
+
+int mvn_plan_store_size(void) { return (int)PlanStore::get().size(); }
+int mvn_plan_store_empty(void) { return PlanStore::get().empty() ? 1 : 0; }
+int mvn_plan_store_clear(void) {
+  return guarded("mvn_plan_store_clear", [&] { PlanStore::get().clear(); });
+}
+
+int mvn_plan_describe(int device, const int dims[3], int out[8]) {
+  return guarded("mvn_plan_describe", [&] {
+    std::shared_ptr<Plan3D> p = PlanStore::get().add(pick_device(device), to_shape(dims));
+    out[0] = p->L.h;
+    out[1] = p->L.C;
+    out[2] = p->L.RP;
+    out[3] = p->L.even ? 1 : 0;
+    out[4] = p->g_rows.T;
+    out[5] = p->g_ax1.T;
+    out[6] = p->g_ax0.T;
+    out[7] = p->ax2.view.nstages;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// whole transforms on host buffers
+// ---------------------------------------------------------------------------------------------
+struct FftScratch {
+  std::shared_ptr<Plan3D> plan;
+  be::stream_t s = nullptr;
+  float* vol = nullptr;
+  cfloat* nyq = nullptr;
+  FftScratch(int dev, const int* dims) {
+    be::set_device(dev);
+    plan = PlanStore::get().add(dev, to_shape(dims));
+    s = be::stream_create();
+    vol = (float*)be::dmalloc(plan->main_bytes());
+    be::dzero(vol, plan->main_bytes(), s);
+    if (plan->nyq_bytes()) {
+      nyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
+      be::dzero(nyq, plan->nyq_bytes(), s);
+    }
+  }
+  ~FftScratch() {
+    try {
+      be::stream_sync(s);
+    } catch (...) {
+    }
+    be::dfree(vol);
+    be::dfree(nyq);
+    be::stream_destroy(s);
+  }
+};
+
+int mvn_fft3_r2c(int device, const int dims[3], const float* real, float* spec) {
+  return guarded("mvn_fft3_r2c", [&] {
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    FftScratch f(dev, dims);
+    const Layout& L = f.plan->L;
+    be::h2d_2d(f.vol, (size_t)L.RP * 4, real, (size_t)L.d2 * 4, (size_t)L.d2 * 4, L.rows, f.s);
+    f.plan->forward(f.vol, f.nyq, f.s);
+    const int nc = L.d2 / 2 + 1;
+    // main bins -> first C complex of every FFTW row; Nyquist plane -> last bin
+    be::d2h_2d(spec, (size_t)nc * 8, f.vol, (size_t)L.C * 8, (size_t)L.C * 8, L.rows, f.s);
+    if (L.even) be::d2h_2d(spec + 2 * (size_t)L.C, (size_t)nc * 8, f.nyq, 8, 8, L.rows, f.s);
+    be::stream_sync(f.s);
+  });
+}
+
+int mvn_fft3_c2r(int device, const int dims[3], const float* spec, float* real) {
+  return guarded("mvn_fft3_c2r", [&] {
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    FftScratch f(dev, dims);
+    const Layout& L = f.plan->L;
+    const int nc = L.d2 / 2 + 1;
+    be::h2d_2d(f.vol, (size_t)L.C * 8, spec, (size_t)nc * 8, (size_t)L.C * 8, L.rows, f.s);
+    if (L.even) be::h2d_2d(f.nyq, 8, spec + 2 * (size_t)L.C, (size_t)nc * 8, 8, L.rows, f.s);
+    f.plan->backward(f.vol, f.nyq, 1.f, f.s);
+    be::d2h_2d(real, (size_t)L.d2 * 4, f.vol, (size_t)L.RP * 4, (size_t)L.d2 * 4, L.rows, f.s);
+    be::stream_sync(f.s);
+  });
+}
+
+int mvn_fft3_time(int device, const int dims[3], int direction, int reps, float* ms) {
+  return guarded("mvn_fft3_time", [&] {
+    if (reps < 1) throw std::invalid_argument("reps must be >= 1");
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    FftScratch f(dev, dims);
+    const Layout& L = f.plan->L;
+    {  // non-trivial contents (zeros flatter the clock: guide 5.4 rule 25)
+      std::vector<float> host(L.real_floats());
+      unsigned x = 12345u;
+      for (size_t i = 0; i < host.size(); ++i) {
+        x = x * 1664525u + 1013904223u;
+        host[i] = (float)(x >> 8) * (1.0f / 16777216.0f) - 0.5f;
+      }
+      be::h2d(f.vol, host.data(), host.size() * 4, f.s);
+      be::stream_sync(f.s);
+    }
+    const float keep = 1.0f / (float)L.logical();
+    auto run = [&] {
+      if (direction == 0)
+        f.plan->forward(f.vol, f.nyq, f.s);
+      else
+        f.plan->backward(f.vol, f.nyq, keep, f.s);
+    };
+    run();  // warm-up
+    be::event_t a = be::event_create(), b = be::event_create();
+    be::event_record(a, f.s);
+    for (int i = 0; i < reps; ++i) run();
+    be::event_record(b, f.s);
+    be::event_sync(b);
+    *ms = be::event_elapsed_ms(a, b) / (float)reps;
+    be::event_destroy(a);
+    be::event_destroy(b);
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// resident engine
+// ---------------------------------------------------------------------------------------------
+int mvn_engine_create(int device, const int dims[3], int num_views, mvn_engine** out) {
+  return guarded("mvn_engine_create", [&] {
+    if (!out) throw std::invalid_argument("null out");
+    *out = nullptr;
+    std::unique_ptr<mvn_engine> h(new mvn_engine());
+    h->impl.reset(new Engine(pick_device(device), to_shape(dims), num_views));
+    *out = h.release();
+  });
+}
+
+int mvn_engine_destroy(mvn_engine* e) {
+  return guarded("mvn_engine_destroy", [&] { delete e; });
+}
+
+#define MVN_ENGINE_CALL(name, ...)                                 \
+  return guarded(name, [&] {                                       \
+    if (!e || !e->impl) throw std::invalid_argument("null engine"); \
+    Engine& E = *e->impl;                                          \
+    (void)E;                                                       \
+    __VA_ARGS__;                                                   \
+  })
+
+int mvn_engine_set_view(mvn_engine* e, int v, const float* image, const float* weights,
+                        const float* kernel1, const int k1dims[3], const float* kernel2,
+                        const int k2dims[3]) {
+  MVN_ENGINE_CALL("mvn_engine_set_view", {
+    if (!image || !weights || !kernel1 || !kernel2 || !k1dims || !k2dims)
+      throw std::invalid_argument("null argument");
+    E.set_view(v, image, weights, kernel1, k1dims, kernel2, k2dims);
+  });
+}
+
+int mvn_engine_set_psi(mvn_engine* e, const float* psi) {
+  MVN_ENGINE_CALL("mvn_engine_set_psi", E.set_psi(psi));
+}
+
+int mvn_engine_get_psi(mvn_engine* e, float* psi) {
+  MVN_ENGINE_CALL("mvn_engine_get_psi", E.get_psi(psi));
+}
+
+int mvn_engine_iterate(mvn_engine* e, int iterations, double lambda, float min_value) {
+  MVN_ENGINE_CALL("mvn_engine_iterate", E.iterate(iterations, lambda, min_value));
+}
+
+int mvn_engine_compute_delta(mvn_engine* e, double lambda, float min_value) {
+  MVN_ENGINE_CALL("mvn_engine_compute_delta", E.compute_delta(lambda, min_value));
+}
+
+int mvn_engine_apply_delta(mvn_engine* e) {
+  MVN_ENGINE_CALL("mvn_engine_apply_delta", E.apply_delta());
+}
+
+int mvn_engine_delta_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats) {
+  MVN_ENGINE_CALL("mvn_engine_delta_ptr", {
+    *dev_ptr = E.delta_ptr();
+    *n_floats = E.volume_floats();
+  });
+}
+
+int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats) {
+  MVN_ENGINE_CALL("mvn_engine_psi_ptr", {
+    *dev_ptr = E.psi_ptr();
+    *n_floats = E.volume_floats();
+  });
+}
+
+int mvn_engine_stream(mvn_engine* e, void** hip_stream) {
+  MVN_ENGINE_CALL("mvn_engine_stream", *hip_stream = E.stream());
+}
+
+int mvn_engine_sync(mvn_engine* e) { MVN_ENGINE_CALL("mvn_engine_sync", E.sync()); }
+
+int mvn_engine_time_iterate(mvn_engine* e, int iterations, double lambda, float min_value,
+                            float* ms) {
+  MVN_ENGINE_CALL("mvn_engine_time_iterate", {
+    be::set_device(E.device());
+    be::event_t a = be::event_create(), b = be::event_create();
+    be::event_record(a, E.stream());
+    E.iterate(iterations, lambda, min_value);
+    be::event_record(b, E.stream());
+    be::event_sync(b);
+    *ms = be::event_elapsed_ms(a, b);
+    be::event_destroy(a);
+    be::event_destroy(b);
+    E.sync();
+  });
+}
+
+int mvn_engine_profile(mvn_engine* e, int enable) {
+  MVN_ENGINE_CALL("mvn_engine_profile", {
+    E.sync();
+    E.profiler().reset();
+    E.profiler().enabled = enable != 0;
+  });
+}
+
+int mvn_engine_profile_read(mvn_engine* e, int kind, double* total_ms, long* launches) {
+  MVN_ENGINE_CALL("mvn_engine_profile_read", {
+    if (kind < 0 || kind >= KK_COUNT) throw std::out_of_range("kernel kind");
+    E.sync();
+    *total_ms = E.profiler().total_ms[kind];
+    *launches = E.profiler().count[kind];
+  });
+}
+
+int mvn_kernel_kind_count(void) { return KK_COUNT; }
+const char* mvn_kernel_kind_name(int kind) { return kernel_kind_name(kind); }
+
+size_t mvn_engine_B(mvn_engine* e) { return (e && e->impl) ? e->impl->layout().B() : 0; }
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// mvn_backend.hpp -- the thin device interface the engine is written against.
+//
+// Product build (libmultiviewnative.so): implemented in mvn_kernels.hip on HIP streams and
+// gfx950 kernels.  There is NO CPU implementation in the product.
+// Test-only build (libmvn_emu.so, -DMVN_HOST_EMU): implemented in mvn_backend_emu.cpp, where
+// "device memory" is host memory and a launch runs the same workgroup bodies one block at a
+// time on the CPU.  It exists to validate plans, index math and the RL driver on a box without
+// a GPU; it is never linked into, or loaded by, the product library.
+#pragma once
+
+#include <cstddef>
+
+#include "mvn_pass_bodies.hpp"
+
+namespace mvn {
+namespace be {
+
+typedef void* stream_t;
+typedef void* event_t;
+
+const char* backend_name();
+
+int device_count();
+void set_device(int dev);
+int get_device();
+void device_name(int dev, char* name256);
+long long device_total_mem(int dev);
+void device_mem_info(size_t* free_b, size_t* total_b);
+void device_arch(int dev, int* major, int* minor);
+
+void* dmalloc(size_t bytes);
+void dfree(void* p);
+void h2d(void* d, const void* h, size_t bytes, stream_t s);
+void d2h(void* h, const void* d, size_t bytes, stream_t s);
+void d2d(void* dst, const void* src, size_t bytes, stream_t s);
+void h2d_2d(void* d, size_t dpitch, const void* h, size_t hpitch, size_t width, size_t height,
+            stream_t s);
+void d2h_2d(void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, size_t height,
+            stream_t s);
+void d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+            stream_t s);
+void dzero(void* d, size_t bytes, stream_t s);
+
+stream_t stream_create();
+void stream_destroy(stream_t s);
+void stream_sync(stream_t s);
+
+event_t event_create();
+void event_destroy(event_t e);
+void event_record(event_t e, stream_t s);
+void event_sync(event_t e);
+float event_elapsed_ms(event_t a, event_t b);
+
+// ---- kernel launches --------------------------------------------------------------------
+void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int nthreads, size_t lds_bytes,
+                     stream_t s);
+void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int nthreads, size_t lds_bytes,
+                     stream_t s);
+void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
+                    size_t lds_bytes, stream_t s);
+
+// target[(z-kz/2 mod D0, y-ky/2 mod D1, x-kx/2 mod D2)] = kernel[z][y][x] * scale
+// (device-side wrapped_insert_at_point, inc/padd_utils.h:11-40; the reference's GPU twin is
+// fftShiftKernel, src/multiviewnative.cu:154-192).  target has row pitch `pitch` floats.
+void launch_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
+                        int D1, int D2, long pitch, float scale, stream_t s);
+
+// stand-alone pointwise ops on flat arrays (legacy ABI: compute_quotient / compute_final_values)
+void launch_divide(const float* view, float* inout, size_t n, stream_t s);
+void launch_update(float* psi, const float* integral, const float* weights, size_t n,
+                   double lambda, float min_value, stream_t s);
+// psi += delta  (applies the all-reduced correction in simultaneous mode)
+void launch_axpy1(float* psi, const float* delta, size_t n, stream_t s);
+
+}  // namespace be
+}  // namespace mvn

@@ -1,0 +1,152 @@
+// mvn_backend_emu.cpp -- TEST-ONLY host emulation of the device backend (-DMVN_HOST_EMU).
+//
+// Built into libmvn_emu.so, never into the product library.  "Device memory" is host memory;
+// a launch runs the very same workgroup bodies (mvn_pass_bodies.hpp) one block after the other
+// with a single work-item enumerator per block, so plans, tables, addressing and the RL driver
+// can be validated against the oracle and numpy on a box without a GPU.  It says nothing about
+// barriers or races -- those are covered by the -m gpu parity tests.
+#ifndef MVN_HOST_EMU
+#error "mvn_backend_emu.cpp is only for the MVN_HOST_EMU test build"
+#endif
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "mvn_backend.hpp"
+
+namespace mvn {
+namespace be {
+
+const char* backend_name() { return "host-emulation (test only)"; }
+
+int device_count() { return 1; }
+void set_device(int) {}
+int get_device() { return 0; }
+void device_name(int, char* name256) {
+  std::memset(name256, 0, 256);
+  std::strcpy(name256, "mvn host emulation");
+}
+long long device_total_mem(int) { return 8LL << 30; }
+void device_mem_info(size_t* f, size_t* t) {
+  *f = (size_t)8 << 30;
+  *t = (size_t)8 << 30;
+}
+void device_arch(int, int* major, int* minor) {
+  *major = 0;
+  *minor = 0;
+}
+
+void* dmalloc(size_t bytes) {
+  void* p = std::malloc(bytes ? bytes : 1);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void dfree(void* p) { std::free(p); }
+void h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
+void d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }
+void d2d(void* dst, const void* src, size_t bytes, stream_t) { std::memmove(dst, src, bytes); }
+void h2d_2d(void* d, size_t dpitch, const void* h, size_t hpitch, size_t width, size_t height,
+            stream_t) {
+  for (size_t r = 0; r < height; ++r)
+    std::memcpy((char*)d + r * dpitch, (const char*)h + r * hpitch, width);
+}
+void d2h_2d(void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, size_t height,
+            stream_t) {
+  for (size_t r = 0; r < height; ++r)
+    std::memcpy((char*)h + r * hpitch, (const char*)d + r * dpitch, width);
+}
+void d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+            stream_t) {
+  for (size_t r = 0; r < height; ++r)
+    std::memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
+}
+void dzero(void* d, size_t bytes, stream_t) { std::memset(d, 0, bytes); }
+
+stream_t stream_create() { return (stream_t)1; }
+void stream_destroy(stream_t) {}
+void stream_sync(stream_t) {}
+
+struct EmuEvent {
+  std::chrono::steady_clock::time_point t;
+};
+event_t event_create() { return new EmuEvent(); }
+void event_destroy(event_t e) { delete (EmuEvent*)e; }
+void event_record(event_t e, stream_t) { ((EmuEvent*)e)->t = std::chrono::steady_clock::now(); }
+void event_sync(event_t) {}
+float event_elapsed_ms(event_t a, event_t b) {
+  return std::chrono::duration<float, std::milli>(((EmuEvent*)b)->t - ((EmuEvent*)a)->t).count();
+}
+
+void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
+                     stream_t) {
+#pragma omp parallel
+  {
+    std::vector<char> lds(lds_bytes + 64);
+#pragma omp for schedule(static)
+    for (long t = 0; t < ntiles; ++t) {
+      if (even)
+        rows_r2c_even_body(p, t, 0, 1, (cfloat*)lds.data());
+      else
+        rows_r2c_odd_body(p, t, 0, 1, (cfloat*)lds.data());
+    }
+  }
+}
+
+void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
+                     stream_t) {
+#pragma omp parallel
+  {
+    std::vector<char> lds(lds_bytes + 64);
+#pragma omp for schedule(static)
+    for (long t = 0; t < ntiles; ++t) {
+      if (even)
+        rows_c2r_even_body(p, t, 0, 1, (cfloat*)lds.data());
+      else
+        rows_c2r_odd_body(p, t, 0, 1, (cfloat*)lds.data());
+    }
+  }
+}
+
+void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t lds_bytes,
+                    stream_t) {
+#pragma omp parallel
+  {
+    std::vector<char> lds(lds_bytes + 64);
+#pragma omp for schedule(static)
+    for (long b = 0; b < nblocks; ++b) {
+      cfloat* l = (cfloat*)lds.data();
+      if (mode == MVN_ST_FWD) strided_body<MVN_ST_FWD>(p, b, 0, 1, l);
+      if (mode == MVN_ST_INV) strided_body<MVN_ST_INV>(p, b, 0, 1, l);
+      if (mode == MVN_ST_FWD_MUL_INV) strided_body<MVN_ST_FWD_MUL_INV>(p, b, 0, 1, l);
+    }
+  }
+}
+
+void launch_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
+                        int D1, int D2, long pitch, float scale, stream_t) {
+  const long total = (long)k0 * k1 * k2;
+  for (long i = 0; i < total; ++i) mvn_scatter_psf_item(kernel, k0, k1, k2, target, D0, D1, D2, pitch, scale, i);
+}
+
+void launch_divide(const float* view, float* inout, size_t n, stream_t) {
+  for (size_t i = 0; i < n; ++i) inout[i] = mvn_quotient(view[i], inout[i]);
+}
+
+void launch_update(float* psi, const float* integral, const float* weights, size_t n,
+                   double lambda, float min_value, stream_t) {
+  const float linv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
+  for (size_t i = 0; i < n; ++i) {
+    float last = psi[i];
+    float next = mvn_next_value(last, integral[i], lambda, linv, min_value);
+    psi[i] = weights[i] * (next - last) + last;
+  }
+}
+
+void launch_axpy1(float* psi, const float* delta, size_t n, stream_t) {
+  for (size_t i = 0; i < n; ++i) psi[i] += delta[i];
+}
+
+}  // namespace be
+}  // namespace mvn

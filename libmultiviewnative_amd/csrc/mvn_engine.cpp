@@ -1,0 +1,518 @@
+// mvn_engine.cpp -- see mvn_engine.hpp
+#include "mvn_engine.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace mvn {
+
+static const size_t kLdsSoftBudget = 64 * 1024;   // two workgroups per CU (160 KiB LDS)
+static const size_t kLdsHardBudget = 160 * 1024;  // one workgroup may own the whole CU
+
+const char* kernel_kind_name(int k) {
+  static const char* names[KK_COUNT] = {"rows_r2c",    "rows_c2r",  "axis1_fwd",
+                                        "axis1_inv",   "axis0_fused", "axis0_fwd",
+                                        "axis0_inv",   "nyquist",   "other"};
+  return (k >= 0 && k < KK_COUNT) ? names[k] : "?";
+}
+
+// ---------------------------------------------------------------------------------------------
+// Profiler
+// ---------------------------------------------------------------------------------------------
+be::event_t Profiler::get_event() {
+  if (!pool_.empty()) {
+    be::event_t e = pool_.back();
+    pool_.pop_back();
+    return e;
+  }
+  return be::event_create();
+}
+
+void Profiler::begin(int kind, be::stream_t s) {
+  if (!enabled) return;
+  Rec r;
+  r.kind = kind;
+  r.a = get_event();
+  r.b = get_event();
+  be::event_record(r.a, s);
+  recs_.push_back(r);
+}
+
+void Profiler::end(be::stream_t s) {
+  if (!enabled || recs_.empty()) return;
+  be::event_record(recs_.back().b, s);
+}
+
+void Profiler::collect() {
+  for (size_t i = 0; i < recs_.size(); ++i) {
+    be::event_sync(recs_[i].b);
+    total_ms[recs_[i].kind] += be::event_elapsed_ms(recs_[i].a, recs_[i].b);
+    count[recs_[i].kind] += 1;
+    pool_.push_back(recs_[i].a);
+    pool_.push_back(recs_[i].b);
+  }
+  recs_.clear();
+}
+
+void Profiler::reset() {
+  collect();
+  for (int k = 0; k < KK_COUNT; ++k) {
+    total_ms[k] = 0;
+    count[k] = 0;
+  }
+}
+
+Profiler::~Profiler() {
+  try {
+    collect();
+  } catch (...) {
+  }
+  for (size_t i = 0; i < pool_.size(); ++i) be::event_destroy(pool_[i]);
+}
+
+struct ProfScope {
+  Profiler* p;
+  be::stream_t s;
+  ProfScope(Profiler* p_, int kind, be::stream_t s_) : p(p_), s(s_) {
+    if (p) p->begin(kind, s);
+  }
+  ~ProfScope() {
+    if (p) p->end(s);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// DevAxis / Plan3D
+// ---------------------------------------------------------------------------------------------
+DevAxis::DevAxis(int n) : host(n) {
+  tw = (cfloat*)be::dmalloc(sizeof(cfloat) * (size_t)n);
+  rev = (int*)be::dmalloc(sizeof(int) * (size_t)n);
+  inv = (int*)be::dmalloc(sizeof(int) * (size_t)n);
+  be::h2d(tw, host.tw.data(), sizeof(cfloat) * (size_t)n, nullptr);
+  be::h2d(rev, host.rev.data(), sizeof(int) * (size_t)n, nullptr);
+  be::h2d(inv, host.inv.data(), sizeof(int) * (size_t)n, nullptr);
+  be::stream_sync(nullptr);
+  view = host.view(tw, rev, inv);
+}
+
+DevAxis::~DevAxis() {
+  be::dfree(tw);
+  be::dfree(rev);
+  be::dfree(inv);
+}
+
+PassGeom Plan3D::pick_geom(int n, bool generic, bool rows) {
+  static const int cand[5] = {16, 8, 4, 2, 1};
+  PassGeom g;
+  bool found = false;
+  for (int pass = 0; pass < 2 && !found; ++pass) {
+    const size_t budget = pass == 0 ? kLdsSoftBudget : kLdsHardBudget;
+    for (int i = 0; i < 5; ++i) {
+      const int T = cand[i];
+      const int TP = rows ? (T | 1) : T;  // odd pitch keeps the row transpose conflict-free
+      const size_t one = (size_t)n * (size_t)TP * sizeof(cfloat);
+      const size_t bytes = one * (generic ? 2 : 1);
+      if (bytes <= budget) {
+        g.T = T;
+        g.TP = TP;
+        g.lds_bytes = bytes;
+        g.lds_alt = generic ? (long)n * TP : 0;
+        found = true;
+        break;
+      }
+    }
+  }
+  if (!found)
+    throw std::invalid_argument("mvn: axis length " + std::to_string(n) +
+                                " does not fit the single-pass LDS FFT (160 KiB)");
+  g.threads = 256;
+  return g;
+}
+
+Plan3D::Plan3D(int dev, int d0, int d1, int d2)
+    : device(dev), L(d0, d1, d2), ax2(L.h), ax1(d1), ax0(d0) {
+  if (L.even) {
+    std::vector<cfloat> roots((size_t)L.h / 2 + 1);
+    for (size_t k = 0; k < roots.size(); ++k) {
+      double a = -2.0 * M_PI * (double)k / (double)d2;
+      roots[k].x = (float)std::cos(a);
+      roots[k].y = (float)std::sin(a);
+    }
+    twr = (cfloat*)be::dmalloc(sizeof(cfloat) * roots.size());
+    be::h2d(twr, roots.data(), sizeof(cfloat) * roots.size(), nullptr);
+    be::stream_sync(nullptr);
+  }
+  g_rows = pick_geom(L.h, ax2.host.generic, true);
+  g_ax1 = pick_geom(d1, ax1.host.generic, false);
+  g_ax0 = pick_geom(d0, ax0.host.generic, false);
+  g_nyq1 = g_ax1;
+  g_nyq0 = g_ax0;
+}
+
+Plan3D::~Plan3D() { be::dfree(twr); }
+
+void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::stream_t s,
+                      Profiler* prof) const {
+  RowsParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.ax = ax2.view;
+  p.twr = twr;
+  p.d2 = L.d2;
+  p.h = L.h;
+  p.C = L.C;
+  p.RP = L.RP;
+  p.rows = (long)L.rows;
+  p.T = g_rows.T;
+  p.TP = g_rows.TP;
+  p.lds_alt = g_rows.lds_alt;
+  p.in_real = in_real;
+  p.out_cplx = out;
+  p.out_nyq = out_nyq;
+  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
+  ProfScope ps(prof, KK_ROWS_R2C, s);
+  be::launch_rows_r2c(p, L.even, ntiles, g_rows.threads, g_rows.lds_bytes, s);
+}
+
+void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
+                      const EpilogueParams& epi, be::stream_t s, Profiler* prof) const {
+  RowsParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.ax = ax2.view;
+  p.twr = twr;
+  p.d2 = L.d2;
+  p.h = L.h;
+  p.C = L.C;
+  p.RP = L.RP;
+  p.rows = (long)L.rows;
+  p.T = g_rows.T;
+  p.TP = g_rows.TP;
+  p.lds_alt = g_rows.lds_alt;
+  p.in_cplx = in;
+  p.in_nyq = in_nyq;
+  p.out_real = out_real;
+  p.epi = epi;
+  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
+  ProfScope ps(prof, KK_ROWS_C2R, s);
+  be::launch_rows_c2r(p, L.even, ntiles, g_rows.threads, g_rows.lds_bytes, s);
+}
+
+static StridedParams make_strided(const DevAxis& ax, const PassGeom& g, cfloat* data,
+                                  const cfloat* spec, long ostride, long estride, long cstride,
+                                  int ncols) {
+  StridedParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.ax = ax.view;
+  p.data = data;
+  p.spec = spec;
+  p.ostride = ostride;
+  p.estride = estride;
+  p.cstride = cstride;
+  p.ncols = ncols;
+  p.T = g.T;
+  p.TP = g.TP;
+  p.lds_alt = g.lds_alt;
+  p.tiles_per_outer = (ncols + g.T - 1) / g.T;
+  return p;
+}
+
+void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof) const {
+  {
+    // main array [d0][d1][C]: lines along d1, tiles of neighbouring bins
+    StridedParams p = make_strided(ax1, g_ax1, data, nullptr, (long)L.d1 * L.C, L.C, 1, L.C);
+    ProfScope ps(prof, mode == MVN_ST_FWD ? KK_AXIS1_FWD : KK_AXIS1_INV, s);
+    be::launch_strided(mode, p, (long)L.d0 * p.tiles_per_outer, g_ax1.threads, g_ax1.lds_bytes, s);
+  }
+  if (L.even) {
+    // Nyquist plane [d0][d1]: lines along d1 are contiguous, neighbouring lines d1 apart
+    StridedParams p = make_strided(ax1, g_nyq1, nyq, nullptr, 0, 1, L.d1, L.d0);
+    ProfScope ps(prof, KK_NYQ, s);
+    be::launch_strided(mode, p, p.tiles_per_outer, g_nyq1.threads, g_nyq1.lds_bytes, s);
+  }
+}
+
+void Plan3D::axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec,
+                   const cfloat* spec_nyq, be::stream_t s, Profiler* prof) const {
+  const int kind = mode == MVN_ST_FWD ? KK_AXIS0_FWD
+                                      : (mode == MVN_ST_INV ? KK_AXIS0_INV : KK_AXIS0_FUSED);
+  {
+    // main array viewed as [d0][d1*C]: lines along d0, all (d1, bin) columns are contiguous
+    const long cols = (long)L.d1 * L.C;
+    if (cols > 0x7fffffffL) throw std::invalid_argument("mvn: d1*d2 too large");
+    StridedParams p = make_strided(ax0, g_ax0, data, spec, 0, cols, 1, (int)cols);
+    ProfScope ps(prof, kind, s);
+    be::launch_strided(mode, p, p.tiles_per_outer, g_ax0.threads, g_ax0.lds_bytes, s);
+  }
+  if (L.even) {
+    StridedParams p = make_strided(ax0, g_nyq0, nyq, spec_nyq, 0, L.d1, 1, L.d1);
+    ProfScope ps(prof, KK_NYQ, s);
+    be::launch_strided(mode, p, p.tiles_per_outer, g_nyq0.threads, g_nyq0.lds_bytes, s);
+  }
+}
+
+void Plan3D::forward(float* vol, cfloat* nyq, be::stream_t s, Profiler* prof) const {
+  rows_r2c(vol, (cfloat*)vol, nyq, s, prof);
+  axis1(MVN_ST_FWD, (cfloat*)vol, nyq, s, prof);
+  axis0(MVN_ST_FWD, (cfloat*)vol, nyq, nullptr, nullptr, s, prof);
+}
+
+void Plan3D::backward(float* vol, cfloat* nyq, float scale, be::stream_t s,
+                      Profiler* prof) const {
+  axis0(MVN_ST_INV, (cfloat*)vol, nyq, nullptr, nullptr, s, prof);
+  axis1(MVN_ST_INV, (cfloat*)vol, nyq, s, prof);
+  EpilogueParams e;
+  std::memset(&e, 0, sizeof(e));
+  e.mode = MVN_EPI_STORE;
+  e.scale = scale;
+  rows_c2r((const cfloat*)vol, nyq, vol, e, s, prof);
+}
+
+void Plan3D::convolve(const float* in_real, cfloat* work, cfloat* work_nyq, const cfloat* spec,
+                      const cfloat* spec_nyq, float* out_real, const EpilogueParams& epi,
+                      be::stream_t s, Profiler* prof) const {
+  rows_r2c(in_real, work, work_nyq, s, prof);
+  axis1(MVN_ST_FWD, work, work_nyq, s, prof);
+  axis0(MVN_ST_FWD_MUL_INV, work, work_nyq, spec, spec_nyq, s, prof);
+  axis1(MVN_ST_INV, work, work_nyq, s, prof);
+  rows_c2r(work, work_nyq, out_real, epi, s, prof);
+}
+
+void Plan3D::psf_spectrum(const float* d_kernel, const int* kdims, float scale, float* spec_vol,
+                          cfloat* spec_nyq, be::stream_t s) const {
+  for (int i = 0; i < 3; ++i) {
+    const int D = i == 0 ? L.d0 : (i == 1 ? L.d1 : L.d2);
+    if (kdims[i] < 1 || kdims[i] > D)
+      throw std::invalid_argument("mvn: kernel extent must be in [1, image extent]");
+  }
+  be::dzero(spec_vol, main_bytes(), s);
+  be::launch_scatter_psf(d_kernel, kdims[0], kdims[1], kdims[2], spec_vol, L.d0, L.d1, L.d2, L.RP,
+                         scale, s);
+  forward(spec_vol, spec_nyq, s, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PlanStore
+// ---------------------------------------------------------------------------------------------
+PlanStore& PlanStore::get() {
+  static PlanStore* inst = new PlanStore();  // leaked on purpose: outlives static destructors
+  return *inst;
+}
+
+static std::array<int, 4> plan_key(int device, const shape_t& s) {
+  std::array<int, 4> k = {{device, s[0], s[1], s[2]}};
+  return k;
+}
+
+std::shared_ptr<Plan3D> PlanStore::add(int device, const shape_t& shape) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto key = plan_key(device, shape);
+  auto it = plans_.find(key);
+  if (it != plans_.end()) return it->second;
+  const int prev = be::get_device();
+  be::set_device(device);
+  std::shared_ptr<Plan3D> p(new Plan3D(device, shape[0], shape[1], shape[2]));
+  be::set_device(prev);
+  plans_[key] = p;
+  return p;
+}
+
+bool PlanStore::has_key(int device, const shape_t& shape) {
+  std::lock_guard<std::mutex> lk(mu_);
+  return plans_.count(plan_key(device, shape)) != 0;
+}
+
+std::shared_ptr<Plan3D> PlanStore::lookup(int device, const shape_t& shape) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = plans_.find(plan_key(device, shape));
+  if (it == plans_.end())
+    throw std::runtime_error("mvn::PlanStore: no plan for " + std::to_string(shape[0]) + "x" +
+                             std::to_string(shape[1]) + "x" + std::to_string(shape[2]));
+  return it->second;
+}
+
+bool PlanStore::empty() {
+  std::lock_guard<std::mutex> lk(mu_);
+  return plans_.empty();
+}
+
+size_t PlanStore::size() {
+  std::lock_guard<std::mutex> lk(mu_);
+  return plans_.size();
+}
+
+void PlanStore::clear() {
+  std::lock_guard<std::mutex> lk(mu_);
+  plans_.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Engine
+// ---------------------------------------------------------------------------------------------
+Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device) {
+  if (num_views < 1) throw std::invalid_argument("mvn: num_views must be >= 1");
+  be::set_device(device_);
+  plan_ = PlanStore::get().add(device_, dims);
+  stream_ = be::stream_create();
+  const size_t mb = plan_->main_bytes();
+  psi_ = (float*)be::dmalloc(mb);
+  work_ = (float*)be::dmalloc(mb);
+  be::dzero(psi_, mb, stream_);
+  be::dzero(work_, mb, stream_);
+  if (plan_->nyq_bytes()) work_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
+  views_.resize((size_t)num_views);
+  be::stream_sync(stream_);
+}
+
+Engine::~Engine() {
+  try {
+    be::set_device(device_);
+    if (stream_) be::stream_sync(stream_);
+  } catch (...) {
+  }
+  for (size_t v = 0; v < views_.size(); ++v) {
+    be::dfree(views_[v].image);
+    be::dfree(views_[v].weights);
+    be::dfree(views_[v].spec1);
+    be::dfree(views_[v].nyq1);
+    be::dfree(views_[v].spec2);
+    be::dfree(views_[v].nyq2);
+  }
+  be::dfree(psi_);
+  be::dfree(work_);
+  be::dfree(work_nyq_);
+  be::dfree(delta_);
+  if (stream_) be::stream_destroy(stream_);
+}
+
+void Engine::upload_volume(float* dst, const float* host) {
+  const Layout& L = plan_->L;
+  if (L.RP == L.d2)
+    be::h2d(dst, host, L.logical() * sizeof(float), stream_);
+  else
+    be::h2d_2d(dst, (size_t)L.RP * sizeof(float), host, (size_t)L.d2 * sizeof(float),
+               (size_t)L.d2 * sizeof(float), L.rows, stream_);
+}
+
+void Engine::set_view(int v, const float* image, const float* weights, const float* kernel1,
+                      const int* k1dims, const float* kernel2, const int* k2dims) {
+  if (v < 0 || v >= (int)views_.size()) throw std::out_of_range("mvn: view index");
+  be::set_device(device_);
+  ViewSlot& s = views_[(size_t)v];
+  const size_t mb = plan_->main_bytes(), nb = plan_->nyq_bytes();
+  if (!s.image) {
+    s.image = (float*)be::dmalloc(mb);
+    s.weights = (float*)be::dmalloc(mb);
+    s.spec1 = (float*)be::dmalloc(mb);
+    s.spec2 = (float*)be::dmalloc(mb);
+    be::dzero(s.image, mb, stream_);
+    be::dzero(s.weights, mb, stream_);
+    if (nb) {
+      s.nyq1 = (cfloat*)be::dmalloc(nb);
+      s.nyq2 = (cfloat*)be::dmalloc(nb);
+    }
+  }
+  upload_volume(s.image, image);
+  upload_volume(s.weights, weights);
+  const float scale = (float)(1.0 / (double)plan_->L.logical());  // inc/cpu_convolve.h:271-274
+  const float* ks[2] = {kernel1, kernel2};
+  const int* kd[2] = {k1dims, k2dims};
+  float* specs[2] = {s.spec1, s.spec2};
+  cfloat* nyqs[2] = {s.nyq1, s.nyq2};
+  for (int i = 0; i < 2; ++i) {
+    const size_t kb = sizeof(float) * (size_t)kd[i][0] * (size_t)kd[i][1] * (size_t)kd[i][2];
+    float* dk = (float*)be::dmalloc(kb);
+    be::h2d(dk, ks[i], kb, stream_);
+    try {
+      plan_->psf_spectrum(dk, kd[i], scale, specs[i], nyqs[i], stream_);
+    } catch (...) {
+      be::stream_sync(stream_);
+      be::dfree(dk);
+      throw;
+    }
+    be::stream_sync(stream_);
+    be::dfree(dk);
+  }
+  s.set = true;
+}
+
+void Engine::set_psi(const float* host) {
+  be::set_device(device_);
+  upload_volume(psi_, host);
+  be::stream_sync(stream_);
+}
+
+void Engine::get_psi(float* host) {
+  be::set_device(device_);
+  const Layout& L = plan_->L;
+  if (L.RP == L.d2)
+    be::d2h(host, psi_, L.logical() * sizeof(float), stream_);
+  else
+    be::d2h_2d(host, (size_t)L.d2 * sizeof(float), psi_, (size_t)L.RP * sizeof(float),
+               (size_t)L.d2 * sizeof(float), L.rows, stream_);
+  be::stream_sync(stream_);
+}
+
+// one (view, iteration): the reference's steps 1-4, src/gpu_deconvolve_methods.cuh:491-532
+void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate) {
+  const ViewSlot& s = views_[(size_t)v];
+  if (!s.set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
+  Profiler* prof = prof_.enabled ? &prof_ : nullptr;
+  EpilogueParams e1;
+  std::memset(&e1, 0, sizeof(e1));
+  e1.mode = MVN_EPI_DIVIDE;
+  e1.scale = 1.f;  // 1/N already lives in the PSF spectrum
+  e1.view = s.image;
+  // psi (*) kernel1, then view / blurred, written as the next convolution's input
+  plan_->convolve(psi_, (cfloat*)work_, work_nyq_, (const cfloat*)s.spec1, s.nyq1, work_, e1,
+                  stream_, prof);
+  EpilogueParams e2;
+  std::memset(&e2, 0, sizeof(e2));
+  e2.mode = final_mode;
+  e2.scale = 1.f;
+  e2.psi = psi_;
+  e2.weights = s.weights;
+  e2.delta = delta_;
+  e2.accumulate = accumulate;
+  e2.lambda = lambda;
+  e2.lambda_inv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
+  e2.min_value = min_value;
+  // quotient (*) kernel2, then the psi update fused into the last pass
+  plan_->convolve(work_, (cfloat*)work_, work_nyq_, (const cfloat*)s.spec2, s.nyq2, psi_, e2,
+                  stream_, prof);
+}
+
+void Engine::iterate(int iterations, double lambda, float min_value) {
+  be::set_device(device_);
+  for (int it = 0; it < iterations; ++it)
+    for (int v = 0; v < (int)views_.size(); ++v) conv_pair(v, lambda, min_value, MVN_EPI_UPDATE, 0);
+}
+
+float* Engine::delta_ptr() {
+  if (!delta_) {
+    be::set_device(device_);
+    delta_ = (float*)be::dmalloc(plan_->main_bytes());
+    be::dzero(delta_, plan_->main_bytes(), stream_);
+  }
+  return delta_;
+}
+
+void Engine::compute_delta(double lambda, float min_value) {
+  be::set_device(device_);
+  delta_ptr();
+  for (int v = 0; v < (int)views_.size(); ++v)
+    conv_pair(v, lambda, min_value, MVN_EPI_DELTA, v == 0 ? 0 : 1);
+}
+
+void Engine::apply_delta() {
+  be::set_device(device_);
+  be::launch_axpy1(psi_, delta_ptr(), plan_->L.real_floats(), stream_);
+}
+
+void Engine::sync() {
+  be::set_device(device_);
+  be::stream_sync(stream_);
+  prof_.collect();
+}
+
+}  // namespace mvn

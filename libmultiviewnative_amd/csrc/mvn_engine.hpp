@@ -1,0 +1,195 @@
+// mvn_engine.hpp -- plans, plan_store and the device-resident Richardson-Lucy engine.
+//
+// Replaces, MI355X-first, the reference's
+//   gpu::plan_store<float>                         inc/plan_store.cuh:20-216
+//   inplace_convolve_on_device                     inc/gpu_convolve.cuh:113-142
+//   inplace_gpu_deconvolve_iteration_all_on_device src/gpu_deconvolve_methods.cuh:345-562
+// Everything a call needs (views, weights, both PSF spectra per view, psi, one work volume)
+// stays resident in HBM for the whole call; PSF spectra are computed once per call, not once
+// per (view, iteration) as the reference GPU path does (inc/gpu_convolve.cuh:121-124).
+#pragma once
+
+#include <array>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mvn_backend.hpp"
+#include "mvn_plan.hpp"
+
+namespace mvn {
+
+enum KernelKind {
+  KK_ROWS_R2C = 0,
+  KK_ROWS_C2R,
+  KK_AXIS1_FWD,
+  KK_AXIS1_INV,
+  KK_AXIS0_FUSED,
+  KK_AXIS0_FWD,
+  KK_AXIS0_INV,
+  KK_NYQ,
+  KK_OTHER,
+  KK_COUNT
+};
+const char* kernel_kind_name(int k);
+
+// Optional per-launch timing with events on the launch stream (bench.py's roofline leg).
+class Profiler {
+ public:
+  bool enabled = false;
+  void begin(int kind, be::stream_t s);
+  void end(be::stream_t s);
+  // waits for the recorded events and folds them into the totals
+  void collect();
+  void reset();
+  double total_ms[KK_COUNT] = {0};
+  long count[KK_COUNT] = {0};
+  ~Profiler();
+
+ private:
+  struct Rec {
+    int kind;
+    be::event_t a, b;
+  };
+  std::vector<Rec> recs_;
+  std::vector<be::event_t> pool_;
+  be::event_t get_event();
+};
+
+struct DevAxis {
+  AxisPlanHost host;
+  cfloat* tw = nullptr;
+  int* rev = nullptr;
+  int* inv = nullptr;
+  AxisPlan view;
+  explicit DevAxis(int n);
+  ~DevAxis();
+  DevAxis(const DevAxis&) = delete;
+  DevAxis& operator=(const DevAxis&) = delete;
+};
+
+struct PassGeom {
+  int T = 1, TP = 1, threads = 256;
+  size_t lds_bytes = 0;
+  long lds_alt = 0;
+};
+
+typedef std::array<int, 3> shape_t;
+
+class Plan3D {
+ public:
+  const int device;
+  const Layout L;
+  DevAxis ax2, ax1, ax0;
+  cfloat* twr = nullptr;  // d2-th roots of unity (even d2)
+  PassGeom g_rows, g_ax1, g_ax0, g_nyq1, g_nyq0;
+
+  Plan3D(int device, int d0, int d1, int d2);
+  ~Plan3D();
+
+  size_t main_bytes() const { return L.real_floats() * sizeof(float); }
+  size_t nyq_bytes() const { return L.nyq_cplx() * sizeof(cfloat); }
+
+  // last-axis passes
+  void rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::stream_t s,
+                Profiler* prof = nullptr) const;
+  void rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
+                const EpilogueParams& epi, be::stream_t s, Profiler* prof = nullptr) const;
+  // strided passes on the main array and its Nyquist plane; mode = MvnStridedMode
+  void axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr) const;
+  void axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec, const cfloat* spec_nyq,
+             be::stream_t s, Profiler* prof = nullptr) const;
+
+  // whole transforms, un-normalised, in place on (vol, nyq)
+  void forward(float* vol, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr) const;
+  void backward(float* vol, cfloat* nyq, float scale, be::stream_t s,
+                Profiler* prof = nullptr) const;
+  // cyclic convolution: out <- epilogue( IFFT( FFT(in) * spec ) ); `work` may alias `in`
+  void convolve(const float* in_real, cfloat* work, cfloat* work_nyq, const cfloat* spec,
+                const cfloat* spec_nyq, float* out_real, const EpilogueParams& epi,
+                be::stream_t s, Profiler* prof = nullptr) const;
+  // spectrum of a PSF: zero volume, centre->origin wrapped insert scaled by `scale`, forward FFT
+  void psf_spectrum(const float* d_kernel, const int* kdims, float scale, float* spec_vol,
+                    cfloat* spec_nyq, be::stream_t s) const;
+
+ private:
+  static PassGeom pick_geom(int n, bool generic, bool rows);
+};
+
+// Process-wide plan cache keyed by (device, logical shape); the reference keys by logical shape
+// only (inc/plan_store.cuh:31-33) because it knows a single device.  Thread-safe, unlike the
+// reference's (SURVEY.md 8b "Threading").
+class PlanStore {
+ public:
+  static PlanStore& get();
+  std::shared_ptr<Plan3D> add(int device, const shape_t& shape);
+  bool has_key(int device, const shape_t& shape);
+  // throws std::runtime_error on a miss, like the reference (inc/plan_store.cuh:140-152)
+  std::shared_ptr<Plan3D> lookup(int device, const shape_t& shape);
+  bool empty();
+  size_t size();
+  void clear();
+
+ private:
+  std::mutex mu_;
+  std::map<std::array<int, 4>, std::shared_ptr<Plan3D>> plans_;
+};
+
+struct ViewSlot {
+  float* image = nullptr;
+  float* weights = nullptr;
+  float* spec1 = nullptr;  // main array of the kernel1 spectrum (pre-scaled by 1/N)
+  cfloat* nyq1 = nullptr;
+  float* spec2 = nullptr;
+  cfloat* nyq2 = nullptr;
+  bool set = false;
+};
+
+class Engine {
+ public:
+  Engine(int device, const shape_t& dims, int num_views);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  int device() const { return device_; }
+  const Layout& layout() const { return plan_->L; }
+  int num_views() const { return (int)views_.size(); }
+  be::stream_t stream() const { return stream_; }
+  Profiler& profiler() { return prof_; }
+
+  // host -> device staging (blocking); arrays are dense [d0][d1][d2] floats
+  void set_view(int v, const float* image, const float* weights, const float* kernel1,
+                const int* k1dims, const float* kernel2, const int* k2dims);
+  void set_psi(const float* host);
+  void get_psi(float* host);
+
+  // `iterations` Gauss-Seidel sweeps over all views (the reference order,
+  // src/gpu_deconvolve_methods.cuh:487-535); asynchronous on stream()
+  void iterate(int iterations, double lambda, float min_value);
+  // simultaneous (Jacobi) mode for view sharding: delta <- sum over this engine's views of
+  // w_v (next_v - psi), computed from the current psi without changing it
+  void compute_delta(double lambda, float min_value);
+  void apply_delta();
+  float* delta_ptr();
+  float* psi_ptr() { return psi_; }
+  size_t volume_floats() const { return plan_->L.real_floats(); }
+  void sync();
+
+ private:
+  void conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate);
+  void upload_volume(float* dst, const float* host);
+  int device_;
+  std::shared_ptr<Plan3D> plan_;
+  be::stream_t stream_ = nullptr;
+  float* psi_ = nullptr;
+  float* work_ = nullptr;
+  cfloat* work_nyq_ = nullptr;
+  float* delta_ = nullptr;
+  std::vector<ViewSlot> views_;
+  Profiler prof_;
+};
+
+}  // namespace mvn

@@ -1,0 +1,323 @@
+// mvn_pass_bodies.hpp -- workgroup bodies of the FFT pass kernels and the RL pointwise math.
+//
+// One body = what one workgroup does for one tile; `tid`/`nthreads` enumerate the work items
+// of each phase, phases are separated by MVN_SYNC().  On the device the bodies are wrapped by
+// __global__ kernels (mvn_kernels.hip); on a CPU-only box host_emu.cpp runs them with one
+// "thread" per workgroup to validate the index math against numpy.
+//
+// Reference semantics restated here:
+//   - un-normalised r2c / c2r over the last axis + c2c over the other two
+//     (inc/cufft_utils.cuh:41-75, inc/fft_utils.h:55-104)
+//   - spectrum multiply  F <- F*G  (inc/cuda_kernels.cuh:213-242; the 1/N scale is folded into G)
+//   - quotient           I <- view * float(1.0/I)          (inc/cpu_kernels.h:19-26)
+//   - update             psi <- w*(next-psi)+psi, next from the clamp/Tikhonov chain
+//                                                           (inc/cpu_kernels.h:28-90)
+#pragma once
+
+#include <math.h>
+
+#include "mvn_fft_core.hpp"
+
+enum MvnEpilogue {
+  MVN_EPI_STORE = 0,   // out = x * scale
+  MVN_EPI_DIVIDE = 1,  // out = view * float(1.0 / (x*scale))
+  MVN_EPI_UPDATE = 2,  // psi = w * (next(psi, x*scale) - psi) + psi
+  MVN_EPI_DELTA = 3    // delta (+)= w * (next(psi, x*scale) - psi)     (simultaneous mode)
+};
+
+struct EpilogueParams {
+  int mode;
+  float scale;          // applied to the raw inverse-transform output first
+  const float* view;    // DIVIDE
+  float* psi;           // UPDATE (in/out), DELTA (in)
+  const float* weights; // UPDATE / DELTA
+  float* delta;         // DELTA
+  int accumulate;       // DELTA: 0 -> store, 1 -> add
+  double lambda;        // > 0 selects the Tikhonov branch
+  float lambda_inv;     // float(1.f / lambda)   (inc/cpu_kernels.h:71)
+  float min_value;
+};
+
+// inc/cpu_kernels.h:22-25: TransferT temp = 1. / out; out = in * temp
+MVN_HD float mvn_quotient(float view, float blurred) {
+  float t = (float)(1.0 / (double)blurred);
+  return view * t;
+}
+
+// clamp / regularise chain of inc/cpu_kernels.h:40-49 (lambda == 0) and :75-86 (lambda > 0)
+MVN_HD float mvn_next_value(float last, float integral, double lambda, float lambda_inv,
+                            float min_value) {
+  float value = last * integral;
+  if (value > 0.f) {
+    if (lambda > 0.) value = (float)((double)lambda_inv * (sqrt(1. + 2. * lambda * (double)value) - 1.));
+  } else {
+    value = min_value;
+  }
+  float next;
+  if (isnan(value) || isinf(value))
+    next = min_value;
+  else
+    next = value > min_value ? value : min_value;
+  return next;
+}
+
+MVN_HD void mvn_epilogue(const EpilogueParams& e, float* out, long i, float x) {
+  x *= e.scale;
+  switch (e.mode) {
+    case MVN_EPI_STORE: out[i] = x; break;
+    case MVN_EPI_DIVIDE: out[i] = mvn_quotient(e.view[i], x); break;
+    case MVN_EPI_UPDATE: {
+      float last = e.psi[i];
+      float next = mvn_next_value(last, x, e.lambda, e.lambda_inv, e.min_value);
+      e.psi[i] = e.weights[i] * (next - last) + last;  // inc/cpu_kernels.h:51-52
+    } break;
+    case MVN_EPI_DELTA: {
+      float last = e.psi[i];
+      float next = mvn_next_value(last, x, e.lambda, e.lambda_inv, e.min_value);
+      float d = e.weights[i] * (next - last);
+      e.delta[i] = e.accumulate ? e.delta[i] + d : d;
+    } break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// last-axis passes (contiguous rows).  A tile is T rows; LDS holds them transposed,
+// lds[pos * TP + row], TP odd to keep the transposing accesses conflict-free.
+// ---------------------------------------------------------------------------------------------
+struct RowsParams {
+  AxisPlan ax;        // length h (= d2/2 for even d2, d2 for odd)
+  const cfloat* twr;  // d2-th roots of unity (even d2: real<->half-complex post-processing)
+  int d2, h, C, RP;   // see mvn::Layout
+  long rows;          // d0*d1
+  int T, TP;
+  long lds_alt;       // offset (in cfloat) of the second LDS buffer, 0 if none
+  // r2c: real rows in (pitch RP floats) -> complex rows out (pitch C) + Nyquist plane
+  const float* in_real;
+  cfloat* out_cplx;
+  cfloat* out_nyq;
+  // c2r: complex rows + Nyquist plane in -> real rows out through the epilogue
+  const cfloat* in_cplx;
+  const cfloat* in_nyq;
+  float* out_real;
+  EpilogueParams epi;
+};
+
+// real -> half-complex, even d2: z[j] = x[2j] + i x[2j+1], Z = FFT_h(z), then
+// X[k] = E - i w^k D,  E = (Z[k] + conj Z[h-k])/2,  D = (Z[k] - conj Z[h-k])/2,  w = exp(-2 pi i/d2)
+MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
+  const int h = P.h, T = P.T, TP = P.TP;
+  const long r0 = tile * T;
+  cfloat* buf = lds;
+  cfloat* alt = lds + P.lds_alt;
+  for (int w = tid; w < T * h; w += nthreads) {
+    const int rho = w / h, j = w - rho * h;
+    const long row = r0 + rho;
+    cfloat v = cmake(0.f, 0.f);
+    if (row < P.rows) v = reinterpret_cast<const cfloat*>(P.in_real + row * P.RP)[j];
+    buf[j * TP + rho] = v;
+  }
+  MVN_SYNC();
+  lds_fft_dif<-1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  const int npairs = h / 2 + 1;
+  for (int w = tid; w < npairs * T; w += nthreads) {
+    const int k = w / T, rho = w - k * T;
+    const int m = (h - k) % h;
+    const int pk = P.ax.inv[k], pm = P.ax.inv[m];
+    const cfloat zk = buf[pk * TP + rho];
+    if (k == 0) {
+      buf[pk * TP + rho] = cmake(zk.x + zk.y, 0.f);
+      if (r0 + rho < P.rows) P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);
+    } else {
+      const cfloat zm = buf[pm * TP + rho];
+      const cfloat E = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+      const cfloat D = cmake(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+      const cfloat G = cmul(P.twr[k], D);
+      buf[pk * TP + rho] = cadd(E, cmul_si<-1>(G));
+      if (m != k) buf[pm * TP + rho] = cadd(cconj(E), cmul_si<-1>(cconj(G)));
+    }
+  }
+  MVN_SYNC();
+  for (int w = tid; w < T * h; w += nthreads) {
+    const int rho = w / h, k = w - rho * h;
+    const long row = r0 + rho;
+    if (row < P.rows) P.out_cplx[row * P.C + k] = buf[P.ax.inv[k] * TP + rho];
+  }
+}
+
+// half-complex -> real, even d2: Z[k] = E + i O, E = X[k] + conj X[h-k],
+// O = (X[k] - conj X[h-k]) exp(+2 pi i k/d2); z = IFFT_h(Z); x[2j] = Re z[j], x[2j+1] = Im z[j]
+MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
+  const int h = P.h, T = P.T, TP = P.TP;
+  const long r0 = tile * T;
+  cfloat* buf = lds;
+  cfloat* alt = lds + P.lds_alt;
+  for (int w = tid; w < T * h; w += nthreads) {
+    const int rho = w / h, k = w - rho * h;
+    const long row = r0 + rho;
+    cfloat v = cmake(0.f, 0.f);
+    if (row < P.rows) v = P.in_cplx[row * P.C + k];
+    buf[P.ax.inv[k] * TP + rho] = v;
+  }
+  MVN_SYNC();
+  const int npairs = h / 2 + 1;
+  for (int w = tid; w < npairs * T; w += nthreads) {
+    const int k = w / T, rho = w - k * T;
+    const int m = (h - k) % h;
+    const int pk = P.ax.inv[k], pm = P.ax.inv[m];
+    const cfloat xk = buf[pk * TP + rho];
+    if (k == 0) {
+      // imaginary parts of the DC and Nyquist bins are ignored, as FFTW's c2r does
+      float xh = 0.f;
+      if (r0 + rho < P.rows) xh = P.in_nyq[r0 + rho].x;
+      buf[pk * TP + rho] = cmake(xk.x + xh, xk.x - xh);
+    } else {
+      const cfloat xm = buf[pm * TP + rho];
+      const cfloat E = cmake(xk.x + xm.x, xk.y - xm.y);
+      const cfloat Dk = cmake(xk.x - xm.x, xk.y + xm.y);
+      const cfloat O = cmul(Dk, cconj(P.twr[k]));
+      buf[pk * TP + rho] = cadd(E, cmul_si<+1>(O));
+      if (m != k) buf[pm * TP + rho] = cadd(cconj(E), cmul_si<+1>(cconj(O)));
+    }
+  }
+  MVN_SYNC();
+  lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  for (int w = tid; w < T * h; w += nthreads) {
+    const int rho = w / h, j = w - rho * h;
+    const long row = r0 + rho;
+    if (row < P.rows) {
+      const cfloat z = buf[j * TP + rho];
+      const long i = row * P.RP + 2 * j;
+      mvn_epilogue(P.epi, P.out_real, i, z.x);
+      mvn_epilogue(P.epi, P.out_real, i + 1, z.y);
+    }
+  }
+}
+
+// odd d2: plain complex transform of the real row, first C = (d2+1)/2 bins kept
+MVN_HD void rows_r2c_odd_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
+  const int n = P.h, T = P.T, TP = P.TP;
+  const long r0 = tile * T;
+  cfloat* buf = lds;
+  cfloat* alt = lds + P.lds_alt;
+  for (int w = tid; w < T * n; w += nthreads) {
+    const int rho = w / n, j = w - rho * n;
+    const long row = r0 + rho;
+    float v = 0.f;
+    if (row < P.rows) v = P.in_real[row * P.RP + j];
+    buf[j * TP + rho] = cmake(v, 0.f);
+  }
+  MVN_SYNC();
+  lds_fft_dif<-1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  for (int w = tid; w < T * P.C; w += nthreads) {
+    const int rho = w / P.C, k = w - rho * P.C;
+    const long row = r0 + rho;
+    if (row < P.rows) P.out_cplx[row * P.C + k] = buf[P.ax.inv[k] * TP + rho];
+  }
+}
+
+MVN_HD void rows_c2r_odd_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
+  const int n = P.h, T = P.T, TP = P.TP;
+  const long r0 = tile * T;
+  cfloat* buf = lds;
+  cfloat* alt = lds + P.lds_alt;
+  for (int w = tid; w < T * n; w += nthreads) {
+    const int rho = w / n, k = w - rho * n;
+    const long row = r0 + rho;
+    cfloat v = cmake(0.f, 0.f);
+    if (row < P.rows) {
+      if (k < P.C) {
+        v = P.in_cplx[row * P.C + k];
+        if (k == 0) v.y = 0.f;
+      } else {
+        v = cconj(P.in_cplx[row * P.C + (n - k)]);
+      }
+    }
+    buf[P.ax.inv[k] * TP + rho] = v;
+  }
+  MVN_SYNC();
+  lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  for (int w = tid; w < T * n; w += nthreads) {
+    const int rho = w / n, j = w - rho * n;
+    const long row = r0 + rho;
+    if (row < P.rows) mvn_epilogue(P.epi, P.out_real, row * P.RP + j, buf[j * TP + rho].x);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided-axis passes: lines run along an axis with element stride `estride`, a tile is T
+// neighbouring lines (column stride `cstride`, 1 for the main array so a tile row is one
+// contiguous T*8-byte segment).  lds[pos * TP + col].
+// ---------------------------------------------------------------------------------------------
+enum MvnStridedMode { MVN_ST_FWD = 0, MVN_ST_INV = 1, MVN_ST_FWD_MUL_INV = 2 };
+
+struct StridedParams {
+  AxisPlan ax;
+  cfloat* data;
+  const cfloat* spec;  // FWD_MUL_INV: pre-scaled PSF spectrum, same addressing as data
+  long ostride;        // between outer slabs
+  long estride;        // between elements of a line
+  long cstride;        // between neighbouring lines of a tile
+  int ncols;           // lines per outer slab
+  int tiles_per_outer;
+  int T, TP;
+  long lds_alt;
+};
+
+template <int MODE>
+MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthreads, cfloat* lds) {
+  const int n = P.ax.n, T = P.T, TP = P.TP;
+  const long o = block / P.tiles_per_outer;
+  const int t = (int)(block - o * P.tiles_per_outer);
+  const int c0 = t * T;
+  const int ncol = (P.ncols - c0) < T ? (P.ncols - c0) : T;
+  const long base = o * P.ostride + (long)c0 * P.cstride;
+  cfloat* buf = lds;
+  cfloat* alt = lds + P.lds_alt;
+  for (int w = tid; w < n * T; w += nthreads) {
+    const int j = w / T, c = w - j * T;
+    cfloat v = cmake(0.f, 0.f);
+    if (c < ncol) v = P.data[base + (long)j * P.estride + (long)c * P.cstride];
+    const int pos = (MODE == MVN_ST_INV) ? P.ax.inv[j] : j;
+    buf[pos * TP + c] = v;
+  }
+  MVN_SYNC();
+  if (MODE == MVN_ST_INV) {
+    lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  } else {
+    lds_fft_dif<-1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+    if (MODE == MVN_ST_FWD_MUL_INV) {
+      for (int w = tid; w < n * T; w += nthreads) {
+        const int p = w / T, c = w - p * T;
+        if (c < ncol) {
+          const cfloat g = P.spec[base + (long)P.ax.rev[p] * P.estride + (long)c * P.cstride];
+          buf[p * TP + c] = cmul(buf[p * TP + c], g);
+        }
+      }
+      MVN_SYNC();
+      lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+    }
+  }
+  for (int w = tid; w < n * T; w += nthreads) {
+    const int p = w / T, c = w - p * T;
+    if (c < ncol) {
+      const int row = (MODE == MVN_ST_FWD) ? P.ax.rev[p] : p;
+      P.data[base + (long)row * P.estride + (long)c * P.cstride] = buf[p * TP + c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PSF placement: kernel voxel (z,y,x) -> ((z-k0/2) mod D0, (y-k1/2) mod D1, (x-k2/2) mod D2),
+// integer k/2, so the centre voxel lands on the origin (inc/padd_utils.h:11-40).
+// ---------------------------------------------------------------------------------------------
+MVN_HD void mvn_scatter_psf_item(const float* kernel, int k0, int k1, int k2, float* target,
+                                 int D0, int D1, int D2, long pitch, float scale, long i) {
+  const int x = (int)(i % k2);
+  const int y = (int)((i / k2) % k1);
+  const int z = (int)(i / ((long)k2 * k1));
+  int ix = x - k2 / 2, iy = y - k1 / 2, iz = z - k0 / 2;
+  if (ix < 0) ix += D2;
+  if (iy < 0) iy += D1;
+  if (iz < 0) iz += D0;
+  target[((long)iz * D1 + iy) * pitch + ix] = kernel[i] * scale;
+}

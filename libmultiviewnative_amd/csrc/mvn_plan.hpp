@@ -1,0 +1,124 @@
+// mvn_plan.hpp -- host-side FFT plan construction (pure C++, no HIP).
+//
+// Counterpart of the reference's per-shape plan cache (inc/plan_store.cuh:20-216,
+// inc/plan_store.h:25-235): a plan is everything a pass kernel needs that depends only on
+// the logical shape (d0,d1,d2) -- radix schedule, digit-reversal tables, twiddles, tile and
+// launch geometry.
+//
+// Device data layout ("split-Nyquist", even d2): the real volume is [d0][d1][d2] floats,
+// unpadded, and doubles in place as the half-spectrum [d0][d1][d2/2] complex (bins
+// 0..d2/2-1 of the last axis); the Nyquist bin d2/2 of every row lives in a separate
+// [d0][d1] complex plane.  Together that is exactly the reference's in-place r2c footprint
+// 4*d0*d1*2(d2/2+1) bytes (inc/image_stack_utils.h:24-42), but every row stays aligned and
+// power-of-two extents stay power-of-two.  Odd d2 falls back to a padded row of (d2+1) floats
+// = (d2+1)/2 complex bins and has no Nyquist plane.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mvn_fft_core.hpp"
+
+namespace mvn {
+
+struct AxisPlanHost {
+  int n = 0;
+  std::vector<int> radix;  // DIF order
+  std::vector<int> M;
+  std::vector<cfloat> tw;
+  std::vector<int> rev, inv;
+  bool generic = false;
+  int max_generic_radix = 0;
+
+  static std::vector<int> factorize(int n) {
+    std::vector<int> f;
+    // big inline radices first: fewer stages = fewer LDS round trips
+    while (n % 8 == 0) { f.push_back(8); n /= 8; }
+    while (n % 4 == 0) { f.push_back(4); n /= 4; }
+    while (n % 2 == 0) { f.push_back(2); n /= 2; }
+    for (int p = 3; (long)p * p <= n; p += 2)
+      while (n % p == 0) { f.push_back(p); n /= p; }
+    if (n > 1) f.push_back(n);
+    return f;
+  }
+
+  explicit AxisPlanHost(int n_) : n(n_) {
+    if (n < 1) throw std::invalid_argument("mvn: FFT length must be >= 1");
+    radix = factorize(n);
+    if (radix.empty()) radix.push_back(1);  // n == 1: a single no-op "radix-1" generic stage
+    if ((int)radix.size() > MVN_MAX_STAGES)
+      throw std::invalid_argument("mvn: too many radix stages for length " + std::to_string(n));
+    int prod = 1;
+    for (size_t s = 0; s < radix.size(); ++s) {
+      prod *= radix[s];
+      M.push_back(n / prod);
+      if (!mvn_inline_radix(radix[s])) {
+        generic = true;
+        if (radix[s] > max_generic_radix) max_generic_radix = radix[s];
+      }
+    }
+    tw.resize(n);
+    for (int j = 0; j < n; ++j) {
+      double a = -2.0 * M_PI * (double)j / (double)n;
+      tw[j].x = (float)std::cos(a);
+      tw[j].y = (float)std::sin(a);
+    }
+    rev.resize(n);
+    inv.resize(n);
+    for (int p = 0; p < n; ++p) {
+      int k = 0, w = 1;
+      for (size_t s = 0; s < radix.size(); ++s) {
+        int digit = (p / M[s]) % radix[s];
+        k += digit * w;
+        w *= radix[s];
+      }
+      rev[p] = k;
+      inv[k] = p;
+    }
+  }
+
+  // kernel-visible plan; table pointers are filled by whoever owns the (device) copies
+  AxisPlan view(const cfloat* tw_p, const int* rev_p, const int* inv_p) const {
+    AxisPlan a;
+    a.n = n;
+    a.nstages = (int)radix.size();
+    a.generic = generic ? 1 : 0;
+    for (int s = 0; s < MVN_MAX_STAGES; ++s) {
+      a.radix[s] = s < a.nstages ? radix[s] : 1;
+      a.M[s] = s < a.nstages ? M[s] : 1;
+    }
+    a.tw = tw_p;
+    a.rev = rev_p;
+    a.inv = inv_p;
+    return a;
+  }
+};
+
+// Geometry of the split-Nyquist layout for one logical shape.
+struct Layout {
+  int d0, d1, d2;
+  bool even;    // d2 even -> half-length real trick + Nyquist plane
+  int h;        // length of the complex transform run on the last axis (d2/2 or d2)
+  int C;        // complex bins per row kept in the main array (d2/2, or (d2+1)/2 for odd d2)
+  int RP;       // real row pitch in floats (d2, or d2+1 for odd d2) == 2*C
+  size_t rows;  // d0*d1
+  size_t real_floats() const { return rows * (size_t)RP; }  // floats in the main array
+  size_t nyq_cplx() const { return even ? rows : 0; }       // complex elements in the Nyquist plane
+  size_t logical() const { return rows * (size_t)d2; }
+  // algorithmic bytes "B" of SURVEY.md 8d: the reference's in-place r2c footprint
+  size_t B() const { return 4 * rows * 2 * (size_t)(d2 / 2 + 1); }
+
+  Layout(int a, int b, int c) : d0(a), d1(b), d2(c) {
+    if (a < 1 || b < 1 || c < 1) throw std::invalid_argument("mvn: dims must be >= 1");
+    even = (c % 2 == 0);
+    h = even ? c / 2 : c;
+    C = even ? c / 2 : (c + 1) / 2;
+    RP = 2 * C;
+    rows = (size_t)a * (size_t)b;
+  }
+};
+
+}  // namespace mvn

@@ -1,0 +1,273 @@
+"""ctypes binding of the product shared library ``lib/libmultiviewnative.so``.
+
+This is the only way Python touches the hot path: every call goes through the C-ABI declared
+in ``include/multiviewnative.h`` / ``include/mvn_engine_api.h``.  There is no fallback -- if the
+HIP library has not been built, :func:`lib` raises.
+
+``Binding(path)`` can also wrap the test-only host emulation (``lib/libmvn_emu.so``); only
+``tests/`` does that, to validate plans and index math on a box without a GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .abi import Workspace, c_float_p, c_int_p, fptr, iptr
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+PRODUCT_SO = os.path.join(LIB_DIR, "libmultiviewnative.so")
+EMU_SO = os.path.join(LIB_DIR, "libmvn_emu.so")
+
+REFERENCE_ABI_SYMBOLS = [
+    "inplace_gpu_deconvolve", "inplace_gpu_convolution", "convolution3DfftCUDAInPlace",
+    "convolution3DfftCUDAInPlace_core", "compute_quotient", "compute_final_values",
+    "selectDeviceWithHighestComputeCapability", "getCUDAcomputeCapabilityMinorVersion",
+    "getCUDAcomputeCapabilityMajorVersion", "getNumDevicesCUDA", "getNameDeviceCUDA",
+    "getMemDeviceCUDA",
+]
+ENGINE_ABI_SYMBOLS = [
+    "mvn_last_error", "mvn_backend_name", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
+    "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_engine_create", "mvn_engine_destroy",
+    "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
+    "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
+    "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
+    "mvn_engine_profile", "mvn_engine_profile_read", "mvn_kernel_kind_count",
+    "mvn_kernel_kind_name", "mvn_engine_B",
+]
+
+
+class MvnError(RuntimeError):
+    pass
+
+
+def _dims(shape):
+    return (C.c_int * 3)(*[int(s) for s in shape])
+
+
+class Binding:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise MvnError(
+                "native library %s is missing -- build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (there is no CPU fallback)" % path)
+        self.path = path
+        self.l = C.CDLL(path)
+        l = self.l
+        i3 = C.POINTER(C.c_int)
+        l.mvn_last_error.restype = C.c_char_p
+        l.mvn_backend_name.restype = C.c_char_p
+        l.mvn_kernel_kind_name.restype = C.c_char_p
+        l.mvn_kernel_kind_name.argtypes = [C.c_int]
+        l.inplace_gpu_deconvolve.argtypes = [c_float_p, Workspace, C.c_int]
+        l.inplace_gpu_deconvolve.restype = None
+        for n in ("inplace_gpu_convolution", "convolution3DfftCUDAInPlace"):
+            getattr(l, n).argtypes = [c_float_p, c_int_p, c_float_p, c_int_p, C.c_int]
+            getattr(l, n).restype = None
+        l.convolution3DfftCUDAInPlace_core.argtypes = [C.c_void_p, c_int_p, C.c_void_p, c_int_p, C.c_int]
+        l.convolution3DfftCUDAInPlace_core.restype = None
+        l.compute_quotient.argtypes = [c_float_p, c_float_p, C.c_size_t, C.c_int]
+        l.compute_quotient.restype = None
+        l.compute_final_values.argtypes = [c_float_p, c_float_p, c_float_p, C.c_size_t, C.c_float,
+                                           C.c_double, C.c_int]
+        l.compute_final_values.restype = None
+        l.getNameDeviceCUDA.argtypes = [C.c_int, C.c_char_p]
+        l.getNameDeviceCUDA.restype = None
+        l.getMemDeviceCUDA.argtypes = [C.c_int]
+        l.getMemDeviceCUDA.restype = C.c_longlong
+        l.mvn_plan_store_add.argtypes = [C.c_int, i3]
+        l.mvn_plan_store_has_key.argtypes = [C.c_int, i3]
+        l.mvn_plan_describe.argtypes = [C.c_int, i3, i3]
+        l.mvn_fft3_r2c.argtypes = [C.c_int, i3, c_float_p, c_float_p]
+        l.mvn_fft3_c2r.argtypes = [C.c_int, i3, c_float_p, c_float_p]
+        l.mvn_fft3_time.argtypes = [C.c_int, i3, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        l.mvn_engine_create.argtypes = [C.c_int, i3, C.c_int, C.POINTER(C.c_void_p)]
+        l.mvn_engine_destroy.argtypes = [C.c_void_p]
+        l.mvn_engine_set_view.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, i3,
+                                          c_float_p, i3]
+        l.mvn_engine_set_psi.argtypes = [C.c_void_p, c_float_p]
+        l.mvn_engine_get_psi.argtypes = [C.c_void_p, c_float_p]
+        l.mvn_engine_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_float]
+        l.mvn_engine_compute_delta.argtypes = [C.c_void_p, C.c_double, C.c_float]
+        l.mvn_engine_apply_delta.argtypes = [C.c_void_p]
+        l.mvn_engine_delta_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.mvn_engine_psi_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.mvn_engine_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        l.mvn_engine_sync.argtypes = [C.c_void_p]
+        l.mvn_engine_time_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_float,
+                                              C.POINTER(C.c_float)]
+        l.mvn_engine_profile.argtypes = [C.c_void_p, C.c_int]
+        l.mvn_engine_profile_read.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_long)]
+        l.mvn_engine_B.argtypes = [C.c_void_p]
+        l.mvn_engine_B.restype = C.c_size_t
+
+    # ---- helpers -------------------------------------------------------------------------
+    def check(self, rc):
+        if rc < 0:
+            raise MvnError(self.l.mvn_last_error().decode())
+        return rc
+
+    def backend_name(self):
+        return self.l.mvn_backend_name().decode()
+
+    # ---- reference ABI, numpy in / numpy out ----------------------------------------------
+    def gpu_deconvolve(self, psi, holder, device=0):
+        out = np.ascontiguousarray(psi, dtype=np.float32).copy()
+        self.l.inplace_gpu_deconvolve(fptr(out), holder.ws, device)
+        return out
+
+    def gpu_convolution(self, image, kernel, device=0, legacy=False):
+        im = np.ascontiguousarray(image, dtype=np.float32).copy()
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        idims = np.array(im.shape, np.int32)
+        kdims = np.array(k.shape, np.int32)
+        f = self.l.convolution3DfftCUDAInPlace if legacy else self.l.inplace_gpu_convolution
+        f(fptr(im), iptr(idims), fptr(k), iptr(kdims), device)
+        return im
+
+    def compute_quotient(self, view, blurred, device=0):
+        view = np.ascontiguousarray(view, dtype=np.float32)
+        out = np.ascontiguousarray(blurred, dtype=np.float32).copy()
+        self.l.compute_quotient(fptr(view), fptr(out), out.size, device)
+        return out
+
+    def compute_final_values(self, psi, integral, weight, min_value, lambda_, device=0):
+        psi = np.ascontiguousarray(psi, dtype=np.float32).copy()
+        integral = np.ascontiguousarray(integral, dtype=np.float32)
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        self.l.compute_final_values(fptr(psi), fptr(integral), fptr(weight), psi.size, min_value,
+                                    lambda_, device)
+        return psi
+
+    # ---- transforms ------------------------------------------------------------------------
+    def rfft3(self, x, device=0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        d0, d1, d2 = x.shape
+        spec = np.empty((d0, d1, d2 // 2 + 1), dtype=np.complex64)
+        self.check(self.l.mvn_fft3_r2c(device, _dims(x.shape), fptr(x), fptr(spec.view(np.float32))))
+        return spec
+
+    def irfft3(self, spec, d2, device=0):
+        spec = np.ascontiguousarray(spec, dtype=np.complex64)
+        d0, d1, nc = spec.shape
+        assert nc == d2 // 2 + 1
+        out = np.empty((d0, d1, d2), dtype=np.float32)
+        self.check(self.l.mvn_fft3_c2r(device, _dims((d0, d1, d2)), fptr(spec.view(np.float32)), fptr(out)))
+        return out
+
+    def fft3_time(self, shape, direction=0, reps=10, device=0):
+        ms = C.c_float(0)
+        self.check(self.l.mvn_fft3_time(device, _dims(shape), direction, reps, C.byref(ms)))
+        return ms.value
+
+    def plan_describe(self, shape, device=0):
+        out = (C.c_int * 8)()
+        self.check(self.l.mvn_plan_describe(device, _dims(shape), out))
+        keys = ["h", "C", "RP", "even", "rows_T", "ax1_T", "ax0_T", "n_stages"]
+        return dict(zip(keys, list(out)))
+
+    def engine(self, shape, num_views, device=0):
+        return EngineHandle(self, shape, num_views, device)
+
+
+class EngineHandle:
+    """Resident RL engine (``mvn_engine_*``)."""
+
+    def __init__(self, binding, shape, num_views, device=0):
+        self.b = binding
+        self.shape = tuple(int(s) for s in shape)
+        self.num_views = num_views
+        self.device = device
+        h = C.c_void_p()
+        binding.check(binding.l.mvn_engine_create(device, _dims(shape), num_views, C.byref(h)))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.b.l.mvn_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_view(self, v, image, weights, kernel1, kernel2):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (image, weights, kernel1, kernel2)]
+        assert a[0].shape == self.shape and a[1].shape == self.shape
+        self.b.check(self.b.l.mvn_engine_set_view(self.h, v, fptr(a[0]), fptr(a[1]), fptr(a[2]),
+                                                  _dims(a[2].shape), fptr(a[3]), _dims(a[3].shape)))
+
+    def set_psi(self, psi):
+        p = np.ascontiguousarray(psi, dtype=np.float32)
+        assert p.shape == self.shape
+        self.b.check(self.b.l.mvn_engine_set_psi(self.h, fptr(p)))
+
+    def get_psi(self):
+        out = np.empty(self.shape, np.float32)
+        self.b.check(self.b.l.mvn_engine_get_psi(self.h, fptr(out)))
+        return out
+
+    def iterate(self, iterations, lambda_, min_value, sync=True):
+        self.b.check(self.b.l.mvn_engine_iterate(self.h, iterations, lambda_, min_value))
+        if sync:
+            self.sync()
+
+    def time_iterate(self, iterations, lambda_, min_value):
+        ms = C.c_float(0)
+        self.b.check(self.b.l.mvn_engine_time_iterate(self.h, iterations, lambda_, min_value, C.byref(ms)))
+        return ms.value
+
+    def compute_delta(self, lambda_, min_value):
+        self.b.check(self.b.l.mvn_engine_compute_delta(self.h, lambda_, min_value))
+
+    def apply_delta(self):
+        self.b.check(self.b.l.mvn_engine_apply_delta(self.h))
+
+    def _ptr(self, fn):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.b.check(fn(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def delta_ptr(self):
+        return self._ptr(self.b.l.mvn_engine_delta_ptr)
+
+    def psi_ptr(self):
+        return self._ptr(self.b.l.mvn_engine_psi_ptr)
+
+    def stream(self):
+        p = C.c_void_p()
+        self.b.check(self.b.l.mvn_engine_stream(self.h, C.byref(p)))
+        return p.value
+
+    def sync(self):
+        self.b.check(self.b.l.mvn_engine_sync(self.h))
+
+    def profile(self, enable):
+        self.b.check(self.b.l.mvn_engine_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        out = {}
+        for k in range(self.b.l.mvn_kernel_kind_count()):
+            ms, n = C.c_double(), C.c_long()
+            self.b.check(self.b.l.mvn_engine_profile_read(self.h, k, C.byref(ms), C.byref(n)))
+            out[self.b.l.mvn_kernel_kind_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def B(self):
+        return self.b.l.mvn_engine_B(self.h)
+
+
+_product = None
+
+
+def lib():
+    """The product library.  Raises if it has not been built (no fallback)."""
+    global _product
+    if _product is None:
+        _product = Binding(PRODUCT_SO)
+    return _product

@@ -1,0 +1,174 @@
+"""CPU-only validation of the product's plans, index math and RL driver through the test-only
+host emulation of its device backend (lib/libmvn_emu.so runs the very same workgroup bodies on
+the CPU).  The -m gpu tests repeat the same comparisons on the real kernels."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from libmultiviewnative_amd import native
+from libmultiviewnative_amd.abi import WorkspaceHolder
+from oracle import binding as orc
+from ref_fixtures import Fixture3D, GOLDEN_SUMS, realistic_views, synthetic_views
+
+CSRC = os.path.join(os.path.dirname(native.__file__), "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emu"])
+    return native.Binding(native.EMU_SO)
+
+
+SHAPES = [(8, 8, 8), (4, 6, 10), (13, 17, 19), (16, 18, 14), (6, 10, 15), (32, 20, 64), (3, 5, 2),
+          (12, 7, 9), (1, 1, 4), (2, 3, 1), (24, 40, 22), (64, 64, 64), (5, 4, 46)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_vs_pocketfft(emu, shape):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = emu.rfft3(x)
+    assert np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30) < 5e-6
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_backward_vs_pocketfft(emu, shape):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(shape)
+    spec = np.fft.rfftn(x).astype(np.complex64)
+    ref = np.fft.irfftn(spec.astype(np.complex128), s=shape, axes=(0, 1, 2)) * np.prod(shape)
+    got = emu.irfft3(spec, shape[2])
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
+
+
+def test_ramp_roundtrip_exact(emu):
+    # tests/test_plan_store.cu (GPU twin of test_plan_store.cpp:83-142)
+    x = np.arange(512, dtype=np.float32).reshape(8, 8, 8)
+    back = emu.irfft3(emu.rfft3(x), 8) / np.float32(512)
+    assert np.array_equal(back, x)
+
+
+def test_plan_store_semantics(emu):
+    l = emu.l
+    emu.check(l.mvn_plan_store_clear())
+    assert l.mvn_plan_store_empty() == 1
+    d = (native.C.c_int * 3)(8, 8, 8)
+    assert l.mvn_plan_store_has_key(0, d) == 0
+    emu.check(l.mvn_plan_store_add(0, d))
+    assert l.mvn_plan_store_has_key(0, d) == 1 and l.mvn_plan_store_size() == 1
+    emu.check(l.mvn_plan_store_add(0, d))
+    assert l.mvn_plan_store_size() == 1
+    info = emu.plan_describe((8, 8, 8))
+    assert info["h"] == 4 and info["C"] == 4 and info["RP"] == 8 and info["even"] == 1
+
+
+@pytest.mark.parametrize("name", ["identity", "horizont", "vertical", "depth", "all1"])
+def test_convolution_fixture_sums(emu, name):
+    fx = Fixture3D()
+    out = emu.gpu_convolution(fx.padded_image, getattr(fx, name))
+    got = float(out[fx.interior].astype(np.float64).sum())
+    assert abs(got - GOLDEN_SUMS[name]) / GOLDEN_SUMS[name] < 1e-6
+    ref = orc.cpu_convolution(fx.padded_image, getattr(fx, name))
+    assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("shape,kshape", [((16, 18, 14), (3, 3, 3)), ((13, 17, 19), (5, 3, 7)),
+                                          ((20, 12, 9), (4, 3, 2)), ((8, 8, 8), (8, 8, 8))])
+def test_convolution_vs_oracle(emu, shape, kshape):
+    rng = np.random.default_rng(5)
+    im = rng.uniform(0, 10, shape).astype(np.float32)
+    k = rng.uniform(0, 1, kshape).astype(np.float32)
+    got = emu.gpu_convolution(im, k)
+    ref = orc.cpu_convolution(im, k)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-6
+    assert np.array_equal(got, emu.gpu_convolution(im, k, legacy=True))
+
+
+def test_kernel_larger_than_image_is_rejected(emu, capfd):
+    im = np.ones((4, 4, 4), np.float32)
+    out = emu.gpu_convolution(im, np.ones((5, 3, 3), np.float32))
+    assert np.array_equal(out, im)  # failure leaves the buffer untouched
+    assert "kernel extent" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.006])
+@pytest.mark.parametrize("shape,kshape,nv", [((16, 20, 18), (5, 5, 5), 3), ((13, 17, 19), (3, 5, 3), 2),
+                                             ((8, 12, 10), (3, 3, 3), 1)])
+def test_deconvolve_vs_oracle(emu, shape, kshape, nv, lam):
+    _, views, k1, k2, w, psi0 = realistic_views(shape, nv, kshape)
+    h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+    got = emu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, 2)
+    # stated float32 tolerance: max|d| <= 1e-4 max|psi|, rms <= 1e-5 rms
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-5 * np.sqrt(np.mean(ref ** 2))
+
+
+def test_deconvolve_closed_form_and_loop_invariants(emu):
+    shape = (16, 16, 16)
+    views, k1, k2, w = synthetic_views(shape, 6, 3, 5)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
+    psi0 = np.full(shape, 3.0, np.float32)
+    psi = emu.gpu_deconvolve(psi0, h)
+    assert np.abs(psi - 37.72946).max() < 2e-4 * 37.72946
+    h.with_iterations(0)
+    assert np.array_equal(emu.gpu_deconvolve(psi0, h), psi0)
+    h.with_iterations(1)
+    two = emu.gpu_deconvolve(emu.gpu_deconvolve(psi0, h), h)
+    assert np.array_equal(two, psi)  # N iterations == N x 1 iteration
+
+
+def test_zero_psi_recovers(emu):
+    shape = (8, 8, 8)
+    views, k1, k2, w = synthetic_views(shape, 1, 3, 3)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 1)
+    psi = emu.gpu_deconvolve(np.zeros(shape, np.float32), h)
+    assert np.array_equal(psi, orc.cpu_deconvolve(np.zeros(shape, np.float32), h, 1))
+
+
+def test_mismatched_views_leave_psi_untouched(emu, capfd):
+    views, k1, k2, w = synthetic_views((8, 8, 8), 2, 3, 3)
+    views[1] = np.ones((8, 8, 4), np.float32)
+    w[1] = np.ones((8, 8, 4), np.float32)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 1)
+    psi0 = np.full((8, 8, 8), 2.0, np.float32)
+    assert np.array_equal(emu.gpu_deconvolve(psi0, h), psi0)
+    assert "share image_dims_" in capfd.readouterr().err
+
+
+def test_engine_simultaneous_mode(emu):
+    shape = (12, 10, 14)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (3, 3, 3))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    eng = emu.engine(shape, 3)
+    for v in range(3):
+        eng.set_view(v, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    for _ in range(2):
+        eng.compute_delta(0.006, 1e-4)
+        eng.apply_delta()
+    eng.sync()
+    got = eng.get_psi()
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, 2)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    eng.close()
+
+
+def test_pointwise_entry_points(emu):
+    rng = np.random.default_rng(0)
+    n = 1000
+    view = rng.uniform(0, 5, n).astype(np.float32)
+    blurred = rng.uniform(-1, 5, n).astype(np.float32)
+    blurred[:3] = [0, np.nan, np.inf]
+    a, b = emu.compute_quotient(view, blurred), orc.compute_quotient(view, blurred)
+    assert np.array_equal(a, b, equal_nan=True)
+    psi = rng.uniform(0.5, 10, n).astype(np.float32)
+    integral = rng.uniform(-0.1, 1, n).astype(np.float32)
+    integral[:3] = [np.nan, np.inf, -np.inf]
+    w = rng.uniform(0, 1, n).astype(np.float32)
+    for lam in (0.0, 0.006):
+        assert np.array_equal(emu.compute_final_values(psi, integral, w, 1e-4, lam),
+                              orc.final_values(psi, integral, w, 1e-4, lam))

@@ -53,6 +53,9 @@ MVN_API int mvn_engine_iterate(mvn_engine* e, int iterations, double lambda, flo
 MVN_API int mvn_engine_compute_delta(mvn_engine* e, double lambda, float min_value);
 MVN_API int mvn_engine_apply_delta(mvn_engine* e);
 MVN_API int mvn_engine_delta_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);
+/* make the engine write its delta into caller-owned DEVICE memory (same size as the engine's
+ * own buffer) so a collective library can reduce it in place; NULL restores the internal one */
+MVN_API int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr);
 MVN_API int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);
 MVN_API int mvn_engine_stream(mvn_engine* e, void** hip_stream);
 MVN_API int mvn_engine_sync(mvn_engine* e);

@@ -542,6 +542,10 @@ int mvn_engine_delta_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats) {
   });
 }
 
+int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr) {
+  MVN_ENGINE_CALL("mvn_engine_bind_delta", E.bind_delta((float*)dev_ptr));
+}
+
 int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats) {
   MVN_ENGINE_CALL("mvn_engine_psi_ptr", {
     *dev_ptr = E.psi_ptr();

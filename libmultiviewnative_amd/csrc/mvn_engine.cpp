@@ -381,7 +381,7 @@ Engine::~Engine() {
   be::dfree(psi_);
   be::dfree(work_);
   be::dfree(work_nyq_);
-  be::dfree(delta_);
+  if (!delta_external_) be::dfree(delta_);
   if (stream_) be::stream_destroy(stream_);
 }
 
@@ -495,6 +495,14 @@ float* Engine::delta_ptr() {
     be::dzero(delta_, plan_->main_bytes(), stream_);
   }
   return delta_;
+}
+
+void Engine::bind_delta(float* external) {
+  be::set_device(device_);
+  be::stream_sync(stream_);
+  if (!delta_external_) be::dfree(delta_);
+  delta_ = external;
+  delta_external_ = external != nullptr;
 }
 
 void Engine::compute_delta(double lambda, float min_value) {

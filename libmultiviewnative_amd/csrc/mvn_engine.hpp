@@ -174,6 +174,9 @@ class Engine {
   void compute_delta(double lambda, float min_value);
   void apply_delta();
   float* delta_ptr();
+  // use caller-owned device memory (volume_floats() floats) as the delta buffer, so that a
+  // collective library can all-reduce it in place; nullptr returns to an engine-owned buffer
+  void bind_delta(float* external);
   float* psi_ptr() { return psi_; }
   size_t volume_floats() const { return plan_->L.real_floats(); }
   void sync();
@@ -188,6 +191,7 @@ class Engine {
   float* work_ = nullptr;
   cfloat* work_nyq_ = nullptr;
   float* delta_ = nullptr;
+  bool delta_external_ = false;
   std::vector<ViewSlot> views_;
   Profiler prof_;
 };

@@ -18,6 +18,15 @@
 
 #include "mvn_fft_core.hpp"
 
+// The RL pointwise math mirrors the reference's rounding step by step: no FMA contraction there
+// (the FFT butterflies may contract freely).  gcc has no per-function switch; the emulation
+// build passes -ffp-contract=off globally instead.
+#if defined(__clang__)
+#define MVN_FP_EXACT _Pragma("clang fp contract(off)")
+#else
+#define MVN_FP_EXACT
+#endif
+
 enum MvnEpilogue {
   MVN_EPI_STORE = 0,   // out = x * scale
   MVN_EPI_DIVIDE = 1,  // out = view * float(1.0 / (x*scale))
@@ -40,6 +49,7 @@ struct EpilogueParams {
 
 // inc/cpu_kernels.h:22-25: TransferT temp = 1. / out; out = in * temp
 MVN_HD float mvn_quotient(float view, float blurred) {
+  MVN_FP_EXACT
   float t = (float)(1.0 / (double)blurred);
   return view * t;
 }
@@ -47,6 +57,7 @@ MVN_HD float mvn_quotient(float view, float blurred) {
 // clamp / regularise chain of inc/cpu_kernels.h:40-49 (lambda == 0) and :75-86 (lambda > 0)
 MVN_HD float mvn_next_value(float last, float integral, double lambda, float lambda_inv,
                             float min_value) {
+  MVN_FP_EXACT
   float value = last * integral;
   if (value > 0.f) {
     if (lambda > 0.) value = (float)((double)lambda_inv * (sqrt(1. + 2. * lambda * (double)value) - 1.));
@@ -62,6 +73,7 @@ MVN_HD float mvn_next_value(float last, float integral, double lambda, float lam
 }
 
 MVN_HD void mvn_epilogue(const EpilogueParams& e, float* out, long i, float x) {
+  MVN_FP_EXACT
   x *= e.scale;
   switch (e.mode) {
     case MVN_EPI_STORE: out[i] = x; break;

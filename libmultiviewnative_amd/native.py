@@ -32,7 +32,7 @@ ENGINE_ABI_SYMBOLS = [
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
     "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
-    "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
+    "mvn_engine_bind_delta", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
     "mvn_engine_profile", "mvn_engine_profile_read", "mvn_kernel_kind_count",
     "mvn_kernel_kind_name", "mvn_engine_B",
 ]
@@ -93,6 +93,7 @@ class Binding:
         l.mvn_engine_apply_delta.argtypes = [C.c_void_p]
         l.mvn_engine_delta_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.mvn_engine_psi_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.mvn_engine_bind_delta.argtypes = [C.c_void_p, C.c_void_p]
         l.mvn_engine_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         l.mvn_engine_sync.argtypes = [C.c_void_p]
         l.mvn_engine_time_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_float,
@@ -235,6 +236,9 @@ class EngineHandle:
 
     def delta_ptr(self):
         return self._ptr(self.b.l.mvn_engine_delta_ptr)
+
+    def bind_delta(self, dev_ptr):
+        self.b.check(self.b.l.mvn_engine_bind_delta(self.h, C.c_void_p(dev_ptr)))
 
     def psi_ptr(self):
         return self._ptr(self.b.l.mvn_engine_psi_ptr)

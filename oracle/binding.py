@@ -47,6 +47,10 @@ def _setup(l):
     l.oracle_deconvolve_simultaneous.argtypes = [c_float_p, Workspace, C.c_int]
     l.oracle_deconvolve_simultaneous_step.argtypes = [c_float_p, Workspace, C.c_int, C.c_int,
                                                       c_float_p, C.c_int]
+    l.oracle_last_timing.argtypes = [C.POINTER(C.c_double)]
+    l.oracle_last_timing.restype = None
+    l.oracle_threads.argtypes = [C.c_int]
+    l.oracle_threads.restype = C.c_int
     l.oracle_spatial_convolve.argtypes = [c_float_p, c_int_p, c_float_p, c_int_p, c_float_p]
     for name in ("oracle_rfft3_forward", "oracle_rfft3_backward", "oracle_wrapped_insert",
                  "oracle_compute_quotient", "oracle_final_values",
@@ -133,6 +137,17 @@ def cpu_deconvolve(psi, holder, nthreads=1):
     out = np.ascontiguousarray(psi, dtype=np.float32).copy()
     lib().inplace_cpu_deconvolve(_fp(out), holder.ws, nthreads)
     return out
+
+
+def last_timing():
+    """(psf_setup_seconds, iteration_loop_seconds) of the last cpu_deconvolve call."""
+    t = (C.c_double * 2)()
+    lib().oracle_last_timing(t)
+    return t[0], t[1]
+
+
+def threads(nthreads):
+    return lib().oracle_threads(nthreads)
 
 
 def cpu_deconvolve_simultaneous(psi, holder, nthreads=1):

@@ -1,0 +1,75 @@
+"""The C-ABI library loads on a box without a GPU and exports every symbol the headers declare
+(no compute calls here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from libmultiviewnative_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def product():
+    if not os.path.exists(native.PRODUCT_SO):
+        import __graft_entry__
+        __graft_entry__.build()
+    return C.CDLL(native.PRODUCT_SO)
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#\s*define[^\n]*", "", txt)  # the MVN_API macro definitions themselves
+    return re.findall(r"MVN_API[^;(]*?\b(\w+)\s*\(", txt)
+
+
+def test_headers_and_binding_lists_agree():
+    assert sorted(declared("multiviewnative.h")) == sorted(native.REFERENCE_ABI_SYMBOLS)
+    assert sorted(declared("mvn_engine_api.h")) == sorted(native.ENGINE_ABI_SYMBOLS)
+
+
+def test_every_declared_symbol_is_exported(product):
+    for name in declared("multiviewnative.h") + declared("mvn_engine_api.h"):
+        assert hasattr(product, name), name
+
+
+def test_only_the_abi_is_exported():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", native.PRODUCT_SO]).decode()
+    syms = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    allowed = set(native.REFERENCE_ABI_SYMBOLS) | set(native.ENGINE_ABI_SYMBOLS)
+    extra = {s for s in syms if s not in allowed and not s.startswith("_")}
+    assert not extra, extra
+
+
+def test_no_cpu_entry_points_in_the_product(product):
+    # the CPU path is test infrastructure (oracle/), never shipped: no fallback
+    for name in ("inplace_cpu_deconvolve", "inplace_cpu_convolution"):
+        assert not hasattr(product, name)
+
+
+def test_product_does_not_link_the_oracle():
+    out = subprocess.check_output(["ldd", native.PRODUCT_SO]).decode()
+    assert "oracle" not in out and "mvn_emu" not in out
+    assert "libamdhip64" in out
+
+
+def test_capitalised_names_resolve():
+    for n in ("libMultiViewNative.so", "libMultiviewNative.so"):
+        assert os.path.realpath(os.path.join(native.LIB_DIR, n)) == os.path.realpath(native.PRODUCT_SO)
+
+
+def test_struct_layout_matches_jna():
+    from libmultiviewnative_amd.abi import ViewData, Workspace
+    assert C.sizeof(ViewData) == 64 and C.sizeof(Workspace) == 32
+    assert [f[0] for f in Workspace._fields_] == ["data_", "num_views_", "lambda_", "minValue_", "num_iterations_"]
+    assert (Workspace.num_views_.offset, Workspace.lambda_.offset, Workspace.minValue_.offset,
+            Workspace.num_iterations_.offset) == (8, 16, 24, 28)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(native.MvnError):
+        native.Binding(str(tmp_path / "nope.so"))

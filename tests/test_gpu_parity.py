@@ -1,0 +1,363 @@
+"""Parity of the HIP hot path (through the C-ABI of lib/libmultiviewnative.so) against the CPU
+oracle, the committed golden values and size-independent properties.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from libmultiviewnative_amd.abi import WorkspaceHolder
+from ref_fixtures import Fixture3D, GOLDEN_SUMS, realistic_views, synthetic_views
+
+pytestmark = pytest.mark.gpu
+
+# stated float32 tolerance of the RL result vs the CPU path
+MAX_REL = 1e-4
+RMS_REL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from libmultiviewnative_amd import native
+    b = native.lib()  # raises if the HIP library is missing: no fallback
+    assert b.backend_name() == "hip-gfx950"
+    assert b.l.getNumDevicesCUDA() >= 1
+    return b
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import binding
+    return binding
+
+
+def rel_err(got, ref):
+    d = got.astype(np.float64) - ref.astype(np.float64)
+    return (np.abs(d).max() / max(np.abs(ref).max(), 1e-30),
+            np.sqrt(np.mean(d * d)) / max(np.sqrt(np.mean(ref.astype(np.float64) ** 2)), 1e-30))
+
+
+def test_device_queries(gpu):
+    l = gpu.l
+    n = l.getNumDevicesCUDA()
+    assert n >= 1
+    name = (b"\0" * 256)
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    l.getNameDeviceCUDA(0, buf)
+    assert len(buf.value) > 0
+    assert l.getMemDeviceCUDA(0) > (100 << 30)  # 288 GB HBM3E
+    assert l.getCUDAcomputeCapabilityMajorVersion(0) == 95
+    assert l.getCUDAcomputeCapabilityMinorVersion(0) == 0
+    assert 0 <= l.selectDeviceWithHighestComputeCapability() < n
+
+
+SHAPES = [(8, 8, 8), (4, 6, 10), (13, 17, 19), (16, 18, 14), (6, 10, 15), (32, 20, 64), (3, 5, 2),
+          (12, 7, 9), (1, 1, 4), (2, 3, 1), (24, 40, 22), (64, 64, 64), (5, 4, 46), (128, 96, 160),
+          (40, 30, 250), (7, 542, 6), (27, 25, 49)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_vs_pocketfft(gpu, shape):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = gpu.rfft3(x)
+    assert np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30) < 5e-6
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_backward_vs_pocketfft(gpu, shape):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(shape)
+    spec = np.fft.rfftn(x).astype(np.complex64)
+    ref = np.fft.irfftn(spec.astype(np.complex128), s=shape, axes=(0, 1, 2)) * np.prod(shape)
+    got = gpu.irfft3(spec, shape[2])
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
+
+
+def test_forward_matches_oracle_fft(gpu, orc):
+    x = np.random.default_rng(3).standard_normal((24, 20, 36)).astype(np.float32)
+    a, b = gpu.rfft3(x), orc.rfft3_forward(x, 4)
+    assert np.abs(a - b).max() / np.abs(b).max() < 3e-6
+
+
+def test_ramp_roundtrip(gpu):
+    # tests/test_plan_store.cpp:83-142 demands exact equality of the 8^3 integer ramp after
+    # r2c -> c2r -> /512 from FFTW (pinned on the oracle in test_oracle_fft.py); the reference's GPU
+    # twin (tests/test_plan_store.cu) has no such check.  The HIP butterflies contract to FMAs, so
+    # here the bound is one float32 ulp of the largest value (511 -> 2^-15 * 2 = 6.1e-5).
+    x = np.arange(512, dtype=np.float32).reshape(8, 8, 8)
+    back = gpu.irfft3(gpu.rfft3(x), 8) / np.float32(512)
+    assert np.abs(back - x).max() <= 6.2e-5
+    assert np.array_equal(np.rint(back), x)
+
+
+@pytest.mark.parametrize("shape", [(13, 17, 19), (16, 16, 16), (9, 27, 3), (27, 9, 81), (5, 25, 125),
+                                   (7, 49, 7)])
+def test_roundtrip_mse(gpu, shape):
+    # tests/test_fftw_numerical_stability.cpp:32-664 on the GPU transforms
+    n = int(np.prod(shape))
+    x = np.arange(n, dtype=np.float32).reshape(shape)
+    back = gpu.irfft3(gpu.rfft3(x), shape[2]) / np.float32(n)
+    mse = float(np.mean((back.astype(np.float64) - x) ** 2))
+    assert mse < 1e-4 * max(1.0, (n / 4096.0) ** 2)
+
+
+def test_large_roundtrip_and_parseval(gpu):
+    # full-size property checks (no CPU reference needed): 256^3 roundtrip + Parseval
+    shape = (256, 256, 256)
+    x = np.random.default_rng(11).standard_normal(shape).astype(np.float32)
+    spec = gpu.rfft3(x)
+    back = gpu.irfft3(spec, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 2e-5
+    # Parseval over the half spectrum: bins 1..N/2-1 count twice
+    w = np.full(shape[2] // 2 + 1, 2.0)
+    w[0] = w[-1] = 1.0
+    e_spec = float((np.abs(spec.astype(np.complex128)) ** 2 * w).sum()) / np.prod(shape)
+    e_real = float((x.astype(np.float64) ** 2).sum())
+    assert abs(e_spec - e_real) / e_real < 1e-5
+
+
+def test_plan_store_semantics(gpu):
+    import ctypes as C
+    l = gpu.l
+    gpu.check(l.mvn_plan_store_clear())
+    assert l.mvn_plan_store_empty() == 1
+    d = (C.c_int * 3)(8, 8, 8)
+    assert l.mvn_plan_store_has_key(0, d) == 0
+    gpu.check(l.mvn_plan_store_add(0, d))
+    assert l.mvn_plan_store_has_key(0, d) == 1 and l.mvn_plan_store_size() == 1
+
+
+@pytest.mark.parametrize("name", ["identity", "horizont", "vertical", "depth", "all1"])
+def test_convolution_fixture_sums(gpu, orc, name):
+    # tests/test_gpu_convolve.cpp:9-327: both convolution entry points vs the fixture sums, 1e-5 %
+    fx = Fixture3D()
+    for legacy in (False, True):
+        out = gpu.gpu_convolution(fx.padded_image, getattr(fx, name), legacy=legacy)
+        got = float(out[fx.interior].astype(np.float64).sum())
+        assert abs(got - GOLDEN_SUMS[name]) / GOLDEN_SUMS[name] * 100 < 1e-5 * 100
+        ref = orc.cpu_convolution(fx.padded_image, getattr(fx, name))
+        assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_asymm_delta_reproduces_kernel(gpu):
+    fx = Fixture3D()
+    for name in ("asymm_cross", "asymm_one", "asymm_identity"):
+        kernel = getattr(fx, name)
+        one = gpu.gpu_convolution(fx.padded_one, kernel)[fx.interior]
+        pos = tuple(slice(s // 2 - k // 2, s // 2 - k // 2 + k) for s, k in zip(one.shape, kernel.shape))
+        assert np.array_equal(np.floor(one[pos] + 0.5), kernel)
+        assert abs(float(one.sum()) - float(kernel.sum())) / float(kernel.sum()) < 1e-5
+
+
+def test_identity_16x18x14(gpu):
+    # tests/test_gpu_convolve_impl.cu:422-529: 16x18x14 identity -> per-voxel |d| < 1e-3
+    rng = np.random.default_rng(2)
+    im = rng.uniform(0, 100, (16, 18, 14)).astype(np.float32)
+    k = np.zeros((3, 3, 3), np.float32)
+    k[1, 1, 1] = 1
+    assert np.abs(gpu.gpu_convolution(im, k) - im).max() < 1e-3
+
+
+@pytest.mark.parametrize("shape,kshape", [((16, 18, 14), (3, 3, 3)), ((13, 17, 19), (5, 3, 7)),
+                                          ((20, 12, 9), (4, 3, 2)), ((8, 8, 8), (8, 8, 8)),
+                                          ((64, 48, 80), (15, 15, 15)), ((30, 57, 81), (23, 9, 5))])
+def test_convolution_vs_oracle(gpu, orc, shape, kshape):
+    rng = np.random.default_rng(5)
+    im = rng.uniform(0, 10, shape).astype(np.float32)
+    k = rng.uniform(0, 1, kshape).astype(np.float32)
+    got = gpu.gpu_convolution(im, k)
+    ref = orc.cpu_convolution(im, k, 4)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-6
+
+
+def test_kernel_larger_than_image_is_rejected(gpu, capfd):
+    im = np.ones((4, 4, 4), np.float32)
+    out = gpu.gpu_convolution(im, np.ones((5, 3, 3), np.float32))
+    assert np.array_equal(out, im)
+    assert "kernel extent" in capfd.readouterr().err
+
+
+def test_pointwise_entry_points_bit_exact(gpu, orc):
+    # tests/test_gpu_kernels_impl.cu:57-351: bit-for-bit vs the CPU kernels, incl. 256x255x257-like
+    # ragged sizes and NaN/Inf flow
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 1000, 256 * 255 + 7):
+        view = rng.uniform(0, 5, n).astype(np.float32)
+        blurred = rng.uniform(-1, 5, n).astype(np.float32)
+        blurred[:min(3, n)] = [0, np.nan, np.inf][:min(3, n)]
+        assert np.array_equal(gpu.compute_quotient(view, blurred), orc.compute_quotient(view, blurred),
+                              equal_nan=True)
+        psi = rng.uniform(0.5, 10, n).astype(np.float32)
+        integral = rng.uniform(-0.1, 1, n).astype(np.float32)
+        integral[:min(3, n)] = [np.nan, np.inf, -np.inf][:min(3, n)]
+        w = rng.uniform(0, 1, n).astype(np.float32)
+        for lam in (0.0, 0.006):
+            assert np.array_equal(gpu.compute_final_values(psi, integral, w, 1e-4, lam),
+                                  orc.final_values(psi, integral, w, 1e-4, lam))
+    # constants of the reference test: psi=5, integral=42, w=.1, lambda=.006, min=1e-4
+    c = gpu.compute_final_values(np.full(64, 5, np.float32), np.full(64, 42, np.float32),
+                                 np.full(64, .1, np.float32), 1e-4, 0.0)
+    assert np.all(c == np.float32(0.1) * (np.float32(210) - np.float32(5)) + np.float32(5))
+    q = gpu.compute_quotient(np.ones(100, np.float32), np.full(100, 5, np.float32))
+    assert np.all(q == np.float32(0.2))
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.006])
+@pytest.mark.parametrize("shape,kshape,nv,its", [((16, 20, 18), (5, 5, 5), 3, 3),
+                                                 ((13, 17, 19), (3, 5, 3), 2, 3),
+                                                 ((8, 12, 10), (3, 3, 3), 1, 5),
+                                                 ((64, 64, 64), (9, 9, 9), 3, 10),
+                                                 ((48, 60, 40), (7, 11, 5), 6, 4)])
+def test_deconvolve_vs_oracle(gpu, orc, shape, kshape, nv, its, lam):
+    _, views, k1, k2, w, psi0 = realistic_views(shape, nv, kshape)
+    h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, its)
+    got = gpu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, 8)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+    # the reference's own acceptance: sum of squared differences < 1 (test_gpu_deconvolve_impl.cu:200)
+    assert float(((got.astype(np.float64) - ref) ** 2).sum()) < 1
+
+
+def test_baseline_config0_64cubed(gpu, orc):
+    # BASELINE.json configs[0]: 64^3, 1 view, 3^3 PSF, 5 iterations (reference synthetic data)
+    shape = (64, 64, 64)
+    views, k1, k2, w = synthetic_views(shape, 1, 3, 3)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 5)
+    psi0 = np.full(shape, 3.0, np.float32)
+    got = gpu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, 8)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL
+    assert np.abs(got - 29.40588).max() < 2e-4 * 29.40588
+
+
+def test_baseline_config1_256cubed_vs_oracle(gpu, orc):
+    # BASELINE.json configs[1]: 256^3, 1 view, 15^3 Gaussian PSF, 10 iterations; oracle on all cores
+    from ref_fixtures import gaussian_psf
+    shape = (256, 256, 256)
+    rng = np.random.default_rng(42)
+    truth = np.full(shape, 10.0, np.float32)
+    for _ in range(40):
+        c = [int(rng.uniform(0.1 * s, 0.9 * s)) for s in shape]
+        truth[c[0] - 2:c[0] + 3, c[1] - 2:c[1] + 3, c[2] - 2:c[2] + 3] += rng.uniform(50, 500)
+    psf = gaussian_psf((15, 15, 15), (2.0, 2.0, 3.0))
+    view = orc.cpu_convolution(truth, psf, 8)
+    h = WorkspaceHolder([view], [psf], [np.ascontiguousarray(psf[::-1, ::-1, ::-1])],
+                        [np.ones(shape, np.float32)], 0.006, 1e-4, 10)
+    psi0 = np.full(shape, np.float32(view.mean()), np.float32)
+    got = gpu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, 8)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+
+
+@pytest.mark.parametrize("n_views,want", [(1, 29.40588), (6, 37.72946), (8, 43.75619)])
+def test_synthetic_closed_form(gpu, n_views, want):
+    shape = (32, 32, 32)
+    views, k1, k2, w = synthetic_views(shape, n_views, 21, 25)  # the reference's 21^3 / 25^3 kernels
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
+    psi = gpu.gpu_deconvolve(np.full(shape, 3.0, np.float32), h)
+    assert np.abs(psi - want).max() < 2e-4 * want
+
+
+def test_full_size_512_closed_form(gpu):
+    # BASELINE.json configs[2] size (512^3, 6 views) through a size-independent property: the
+    # reference's synthetic data has a closed-form fixed point in every voxel
+    shape = (512, 512, 512)
+    eng = gpu.engine(shape, 6)
+    views, k1, k2, w = synthetic_views((1, 1, 1), 6, 31, 31)
+    ones = np.ones(shape, np.float32)
+    for v in range(6):
+        eng.set_view(v, np.full(shape, 16.0 + 4.0 * v, np.float32), ones, k1[v], k2[v])
+    eng.set_psi(np.full(shape, 3.0, np.float32))
+    eng.iterate(2, 0.006, 1e-3)
+    psi = eng.get_psi()
+    eng.close()
+    assert np.abs(psi - 37.72946).max() < 2e-4 * 37.72946
+
+
+def test_loop_invariants(gpu, orc):
+    shape = (16, 16, 16)
+    views, k1, k2, w = synthetic_views(shape, 3, 3, 5)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
+    psi0 = np.random.default_rng(1).uniform(1, 4, shape).astype(np.float32)
+    two = gpu.gpu_deconvolve(psi0, h)
+    h.with_iterations(0)  # tests/test_gpu_deconvolve_impl.cu:333-376
+    assert np.array_equal(gpu.gpu_deconvolve(psi0, h), psi0)
+    h.with_iterations(1)
+    assert np.array_equal(gpu.gpu_deconvolve(gpu.gpu_deconvolve(psi0, h), h), two)
+    # zero start: Inf/NaN flow through the FFT and are caught by the clamp chain, as on the CPU
+    z = np.zeros(shape, np.float32)
+    assert np.array_equal(gpu.gpu_deconvolve(z, h), orc.cpu_deconvolve(z, h, 1))
+
+
+def test_errors_leave_psi_untouched(gpu, capfd):
+    views, k1, k2, w = synthetic_views((8, 8, 8), 2, 3, 3)
+    views[1] = np.ones((8, 8, 4), np.float32)
+    w[1] = np.ones((8, 8, 4), np.float32)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 1)
+    psi0 = np.full((8, 8, 8), 2.0, np.float32)
+    assert np.array_equal(gpu.gpu_deconvolve(psi0, h), psi0)
+    assert "share image_dims_" in capfd.readouterr().err
+    views, k1, k2, w = synthetic_views((8, 8, 8), 1, 3, 3)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 1)
+    assert np.array_equal(gpu.gpu_deconvolve(psi0, h, device=99), psi0)
+    assert "no usable GPU" in capfd.readouterr().err
+
+
+def test_device_minus_one_autoselects(gpu, orc):
+    shape = (8, 8, 8)
+    views, k1, k2, w = synthetic_views(shape, 1, 3, 3)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 1)
+    psi0 = np.full(shape, 2.0, np.float32)
+    assert np.allclose(gpu.gpu_deconvolve(psi0, h, device=-1), orc.cpu_deconvolve(psi0, h, 1), rtol=1e-5)
+
+
+def test_simultaneous_mode_vs_oracle(gpu, orc):
+    shape = (24, 20, 28)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 4, (5, 5, 5))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    eng = gpu.engine(shape, 4)
+    for v in range(4):
+        eng.set_view(v, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    for _ in range(3):
+        eng.compute_delta(0.006, 1e-4)
+        eng.apply_delta()
+    got = eng.get_psi()
+    eng.close()
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL
+
+
+def test_device_pointer_convolution_core(gpu, orc):
+    # convolution3DfftCUDAInPlace_core takes DEVICE pointers (src/multiviewnative.cu:243-319);
+    # the caller allocates them with the HIP runtime, as the reference's callers do with CUDA's
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")  # the runtime the product library is already linked to
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+    for shape in ((16, 18, 14), (9, 8, 7)):
+        rng = np.random.default_rng(4)
+        im = rng.uniform(0, 10, shape).astype(np.float32)
+        k = rng.uniform(0, 1, (3, 3, 3)).astype(np.float32)
+        n = im.size + 2 * shape[0] * shape[1]  # the reference's in-place r2c allocation
+        d_im, d_k = C.c_void_p(), C.c_void_p()
+        assert hip.hipMalloc(C.byref(d_im), n * 4) == 0
+        assert hip.hipMalloc(C.byref(d_k), k.size * 4) == 0
+        assert hip.hipMemcpy(d_im, im.ctypes.data_as(C.c_void_p), im.size * 4, H2D) == 0
+        assert hip.hipMemcpy(d_k, k.ctypes.data_as(C.c_void_p), k.size * 4, H2D) == 0
+        idims = np.array(shape, np.int32)
+        kdims = np.array(k.shape, np.int32)
+        gpu.l.convolution3DfftCUDAInPlace_core(d_im, idims.ctypes.data_as(C.POINTER(C.c_int)), d_k,
+                                               kdims.ctypes.data_as(C.POINTER(C.c_int)), 0)
+        got = np.empty(shape, np.float32)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d_im, im.size * 4, D2H) == 0
+        hip.hipFree(d_im)
+        hip.hipFree(d_k)
+        ref = orc.cpu_convolution(im, k, 2)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-6

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "mvn_backend.hpp"
@@ -79,6 +80,16 @@ float event_elapsed_ms(event_t a, event_t b) {
   return std::chrono::duration<float, std::milli>(((EmuEvent*)b)->t - ((EmuEvent*)a)->t).count();
 }
 
+#define MVN_DISPATCH_T(T_, CALL)                                   \
+  switch (T_) {                                                    \
+    case 16: { constexpr int TT = 16; CALL; } break;               \
+    case 8: { constexpr int TT = 8; CALL; } break;                 \
+    case 4: { constexpr int TT = 4; CALL; } break;                 \
+    case 2: { constexpr int TT = 2; CALL; } break;                 \
+    case 1: { constexpr int TT = 1; CALL; } break;                 \
+    default: throw std::invalid_argument("mvn: unsupported tile width"); \
+  }
+
 void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
 #pragma omp parallel
@@ -86,10 +97,12 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t ld
     std::vector<char> lds(lds_bytes + 64);
 #pragma omp for schedule(static)
     for (long t = 0; t < ntiles; ++t) {
-      if (even)
-        rows_r2c_even_body(p, t, 0, 1, (cfloat*)lds.data());
-      else
-        rows_r2c_odd_body(p, t, 0, 1, (cfloat*)lds.data());
+      cfloat* l = (cfloat*)lds.data();
+      if (even) {
+        MVN_DISPATCH_T(p.T, rows_r2c_even_body<TT>(p, t, 0, 1, l));
+      } else {
+        MVN_DISPATCH_T(p.T, rows_r2c_odd_body<TT>(p, t, 0, 1, l));
+      }
     }
   }
 }
@@ -101,10 +114,12 @@ void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t ld
     std::vector<char> lds(lds_bytes + 64);
 #pragma omp for schedule(static)
     for (long t = 0; t < ntiles; ++t) {
-      if (even)
-        rows_c2r_even_body(p, t, 0, 1, (cfloat*)lds.data());
-      else
-        rows_c2r_odd_body(p, t, 0, 1, (cfloat*)lds.data());
+      cfloat* l = (cfloat*)lds.data();
+      if (even) {
+        MVN_DISPATCH_T(p.T, rows_c2r_even_body<TT>(p, t, 0, 1, l));
+      } else {
+        MVN_DISPATCH_T(p.T, rows_c2r_odd_body<TT>(p, t, 0, 1, l));
+      }
     }
   }
 }
@@ -117,9 +132,9 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t 
 #pragma omp for schedule(static)
     for (long b = 0; b < nblocks; ++b) {
       cfloat* l = (cfloat*)lds.data();
-      if (mode == MVN_ST_FWD) strided_body<MVN_ST_FWD>(p, b, 0, 1, l);
-      if (mode == MVN_ST_INV) strided_body<MVN_ST_INV>(p, b, 0, 1, l);
-      if (mode == MVN_ST_FWD_MUL_INV) strided_body<MVN_ST_FWD_MUL_INV>(p, b, 0, 1, l);
+      if (mode == MVN_ST_FWD) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_FWD, TT>(p, b, 0, 1, l))); }
+      if (mode == MVN_ST_INV) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_INV, TT>(p, b, 0, 1, l))); }
+      if (mode == MVN_ST_FWD_MUL_INV) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_FWD_MUL_INV, TT>(p, b, 0, 1, l))); }
     }
   }
 }

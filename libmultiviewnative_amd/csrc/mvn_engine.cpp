@@ -8,7 +8,7 @@
 
 namespace mvn {
 
-static const size_t kLdsSoftBudget = 64 * 1024;   // two workgroups per CU (160 KiB LDS)
+static const size_t kLdsSoftBudget = 80 * 1024;   // two workgroups per CU (160 KiB LDS)
 static const size_t kLdsHardBudget = 160 * 1024;  // one workgroup may own the whole CU
 
 const char* kernel_kind_name(int k) {
@@ -113,12 +113,14 @@ PassGeom Plan3D::pick_geom(int n, bool generic, bool rows) {
       const int T = cand[i];
       const int TP = rows ? (T | 1) : T;  // odd pitch keeps the row transpose conflict-free
       const size_t one = (size_t)n * (size_t)TP * sizeof(cfloat);
-      const size_t bytes = one * (generic ? 2 : 1);
+      const size_t twb = (size_t)n * sizeof(cfloat);  // LDS copy of the twiddle table
+      const size_t bytes = one * (generic ? 2 : 1) + twb;
       if (bytes <= budget) {
         g.T = T;
         g.TP = TP;
         g.lds_bytes = bytes;
         g.lds_alt = generic ? (long)n * TP : 0;
+        g.lds_tw = (long)n * TP * (generic ? 2 : 1);
         found = true;
         break;
       }
@@ -127,7 +129,9 @@ PassGeom Plan3D::pick_geom(int n, bool generic, bool rows) {
   if (!found)
     throw std::invalid_argument("mvn: axis length " + std::to_string(n) +
                                 " does not fit the single-pass LDS FFT (160 KiB)");
-  g.threads = 256;
+  // one radix-8 butterfly per thread and stage when the tile is big enough
+  const long work = (long)n * g.T / 8;
+  g.threads = work >= 512 ? 512 : (work >= 256 ? 256 : (work >= 128 ? 128 : 64));
   return g;
 }
 
@@ -167,6 +171,9 @@ void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::st
   p.T = g_rows.T;
   p.TP = g_rows.TP;
   p.lds_alt = g_rows.lds_alt;
+  p.lds_tw = g_rows.lds_tw;
+  p.hmul = mvn_fastdiv_mul((unsigned)L.h);
+  p.Cmul = mvn_fastdiv_mul((unsigned)L.C);
   p.in_real = in_real;
   p.out_cplx = out;
   p.out_nyq = out_nyq;
@@ -189,6 +196,9 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   p.T = g_rows.T;
   p.TP = g_rows.TP;
   p.lds_alt = g_rows.lds_alt;
+  p.lds_tw = g_rows.lds_tw;
+  p.hmul = mvn_fastdiv_mul((unsigned)L.h);
+  p.Cmul = mvn_fastdiv_mul((unsigned)L.C);
   p.in_cplx = in;
   p.in_nyq = in_nyq;
   p.out_real = out_real;
@@ -213,6 +223,7 @@ static StridedParams make_strided(const DevAxis& ax, const PassGeom& g, cfloat* 
   p.T = g.T;
   p.TP = g.TP;
   p.lds_alt = g.lds_alt;
+  p.lds_tw = g.lds_tw;
   p.tiles_per_outer = (ncols + g.T - 1) / g.T;
   return p;
 }

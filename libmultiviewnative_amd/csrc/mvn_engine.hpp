@@ -74,6 +74,7 @@ struct PassGeom {
   int T = 1, TP = 1, threads = 256;
   size_t lds_bytes = 0;
   long lds_alt = 0;
+  long lds_tw = 0;
 };
 
 typedef std::array<int, 3> shape_t;

@@ -46,10 +46,25 @@ struct AxisPlan {
   int generic;  // 1 if some radix is not one of {2,3,4,5,7,8} (needs the second LDS buffer)
   int radix[MVN_MAX_STAGES];  // DIF order, outermost first
   int M[MVN_MAX_STAGES];      // M[s] = n / (radix[0]*...*radix[s]) = butterfly input stride
+  unsigned Mmul[MVN_MAX_STAGES];  // ceil(2^32 / M[s]): x / M[s] == umulhi(x, Mmul[s]) (mvn_fastdiv)
+  unsigned nmul;                  // same for n
   const cfloat* tw;           // tw[j] = exp(-2 pi i j / n)
   const int* rev;             // rev[p] = k : after DIF, position p holds X[k]
   const int* inv;             // inv[k] = p
 };
+
+// x / d for x < 2^17, 2 <= d <= 2^15 with mul = ceil(2^32 / d) (exact: x * (mul - 2^32/d) < 2^32/d);
+// d == 1 is special-cased.  Every numerator in the pass kernels is < n*T <= 20480.
+MVN_HD unsigned mvn_fastdiv(unsigned x, unsigned d, unsigned mul) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d == 1 ? x : __umulhi(x, mul);
+#else
+  return d == 1 ? x : (unsigned)(((unsigned long long)x * mul) >> 32);
+#endif
+}
+inline unsigned mvn_fastdiv_mul(unsigned d) {
+  return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d);
+}
 
 MVN_HD cfloat cmake(float x, float y) {
   cfloat r;
@@ -199,19 +214,18 @@ MVN_HD bool mvn_inline_radix(int r) {
 // one in-place stage over a tile of T lines.  Work item w -> (line c = w % T, butterfly b).
 // twstep = n / (R * M): tw[j2 * k * twstep] = exp(-2 pi i j2 k / (R M)).
 // ---------------------------------------------------------------------------------------------
-template <int R, int SIGN, bool DIF>
-MVN_HD void stage_inplace(cfloat* buf, int TP, int T, int n, int M, const cfloat* tw, int tid,
-                          int nthreads) {
-  const int nb = n / R;
-  const int nwork = nb * T;
+template <int R, int SIGN, bool DIF, int T>
+MVN_HD void stage_inplace(cfloat* buf, int TP, int n, int M, unsigned Mmul, const cfloat* tw,
+                          int tid, int nthreads) {
+  const int nwork = (n / R) * T;
   const int twstep = n / (R * M);
+  const int stride = M * TP;
   for (int w = tid; w < nwork; w += nthreads) {
-    const int b = w / T;
-    const int c = w - b * T;
-    const int blk = b / M;
+    const int b = w / T;  // T is a compile-time power of two: shift / mask
+    const int c = w % T;
+    const int blk = (int)mvn_fastdiv((unsigned)b, (unsigned)M, Mmul);
     const int j2 = b - blk * M;
     cfloat* p = buf + (blk * R * M + j2) * TP + c;
-    const int stride = M * TP;
     cfloat a[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) a[j] = p[j * stride];
@@ -230,8 +244,8 @@ MVN_HD void stage_inplace(cfloat* buf, int TP, int T, int n, int M, const cfloat
 }
 
 // out-of-place O(R^2) stage for any radix; one work item per output element.
-template <int SIGN, bool DIF>
-MVN_HD void stage_generic(const cfloat* in, cfloat* out, int TP, int T, int n, int R, int M,
+template <int SIGN, bool DIF, int T>
+MVN_HD void stage_generic(const cfloat* in, cfloat* out, int TP, int n, int R, int M,
                           const cfloat* tw, int tid, int nthreads) {
   const int nwork = n * T;
   const int twstep = n / (R * M);  // step of exp(-2 pi i /(R M)) in the length-n table
@@ -260,20 +274,21 @@ MVN_HD void stage_generic(const cfloat* in, cfloat* out, int TP, int T, int n, i
   }
 }
 
-template <int SIGN, bool DIF>
-MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, int T, const AxisPlan& pl, int s,
+template <int SIGN, bool DIF, int T>
+MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, int s,
                            const cfloat* tw, int tid, int nthreads) {
   const int R = pl.radix[s];
   const int M = pl.M[s];
+  const unsigned mm = pl.Mmul[s];
   switch (R) {
-    case 2: stage_inplace<2, SIGN, DIF>(buf, TP, T, pl.n, M, tw, tid, nthreads); break;
-    case 3: stage_inplace<3, SIGN, DIF>(buf, TP, T, pl.n, M, tw, tid, nthreads); break;
-    case 4: stage_inplace<4, SIGN, DIF>(buf, TP, T, pl.n, M, tw, tid, nthreads); break;
-    case 5: stage_inplace<5, SIGN, DIF>(buf, TP, T, pl.n, M, tw, tid, nthreads); break;
-    case 7: stage_inplace<7, SIGN, DIF>(buf, TP, T, pl.n, M, tw, tid, nthreads); break;
-    case 8: stage_inplace<8, SIGN, DIF>(buf, TP, T, pl.n, M, tw, tid, nthreads); break;
+    case 2: stage_inplace<2, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
+    case 3: stage_inplace<3, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
+    case 4: stage_inplace<4, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
+    case 5: stage_inplace<5, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
+    case 7: stage_inplace<7, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
+    case 8: stage_inplace<8, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
     default: {
-      stage_generic<SIGN, DIF>(buf, alt, TP, T, pl.n, R, M, tw, tid, nthreads);
+      stage_generic<SIGN, DIF, T>(buf, alt, TP, pl.n, R, M, tw, tid, nthreads);
       cfloat* t = buf;
       buf = alt;
       alt = t;
@@ -283,22 +298,30 @@ MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, int T, const Axis
 
 // Forward-order stages: natural in -> position p holds X[rev[p]].  `buf` is updated to point at
 // the buffer that holds the result (it flips to `alt` once per generic stage).  The caller must
-// have synchronised the tile before the call; the tile is synchronised on return.
-template <int SIGN>
-MVN_HD void lds_fft_dif(cfloat*& buf, cfloat*& alt, int TP, int T, const AxisPlan& pl,
-                        const cfloat* tw, int tid, int nthreads) {
+// have synchronised the tile before the call; the tile is synchronised on return.  `tw` may
+// point to an LDS copy of the plan's twiddle table.
+template <int SIGN, int T>
+MVN_HD void lds_fft_dif(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
+                        int tid, int nthreads) {
   for (int s = 0; s < pl.nstages; ++s) {
-    stage_dispatch<SIGN, true>(buf, alt, TP, T, pl, s, tw, tid, nthreads);
+    stage_dispatch<SIGN, true, T>(buf, alt, TP, pl, s, tw, tid, nthreads);
     MVN_SYNC();
   }
 }
 
 // Reverse-order stages: position p holds x[rev[p]] on entry -> natural order out.
-template <int SIGN>
-MVN_HD void lds_fft_dit(cfloat*& buf, cfloat*& alt, int TP, int T, const AxisPlan& pl,
-                        const cfloat* tw, int tid, int nthreads) {
+template <int SIGN, int T>
+MVN_HD void lds_fft_dit(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
+                        int tid, int nthreads) {
   for (int s = pl.nstages - 1; s >= 0; --s) {
-    stage_dispatch<SIGN, false>(buf, alt, TP, T, pl, s, tw, tid, nthreads);
+    stage_dispatch<SIGN, false, T>(buf, alt, TP, pl, s, tw, tid, nthreads);
     MVN_SYNC();
   }
+}
+
+// copy the plan's twiddle table into LDS (stage loops then read it with broadcast ds_reads
+// instead of going through the vector memory pipe)
+MVN_HD const cfloat* lds_stage_twiddles(cfloat* dst, const AxisPlan& pl, int tid, int nthreads) {
+  for (int j = tid; j < pl.n; j += nthreads) dst[j] = pl.tw[j];
+  return dst;
 }

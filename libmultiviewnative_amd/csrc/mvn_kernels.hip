@@ -32,28 +32,28 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <bool EVEN>
-__global__ void __launch_bounds__(256) k_rows_r2c(const RowsParams p) {
+template <bool EVEN, int T>
+__global__ void __launch_bounds__(512) k_rows_r2c(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   if (EVEN)
-    rows_r2c_even_body(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+    rows_r2c_even_body<T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
   else
-    rows_r2c_odd_body(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+    rows_r2c_odd_body<T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
 }
 
-template <bool EVEN>
-__global__ void __launch_bounds__(256) k_rows_c2r(const RowsParams p) {
+template <bool EVEN, int T>
+__global__ void __launch_bounds__(512) k_rows_c2r(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   if (EVEN)
-    rows_c2r_even_body(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+    rows_c2r_even_body<T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
   else
-    rows_c2r_odd_body(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+    rows_c2r_odd_body<T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) k_strided(const StridedParams p) {
+template <int MODE, int T>
+__global__ void __launch_bounds__(512) k_strided(const StridedParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
-  strided_body<MODE>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+  strided_body<MODE, T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
 }
 
 __global__ void k_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
@@ -224,56 +224,56 @@ static void ensure_lds(K kernel, size_t lds_bytes) {
 
 static void check_launch(long nblocks, int nthreads, size_t lds_bytes) {
   if (nblocks < 1 || nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
-  if (nthreads < 64 || nthreads > 256 || nthreads % 64) throw std::invalid_argument("mvn: bad block size");
+  if (nthreads < 64 || nthreads > 512 || nthreads % 64) throw std::invalid_argument("mvn: bad block size");
   if (lds_bytes > 160 * 1024) throw std::invalid_argument("mvn: LDS request exceeds 160 KiB");
 }
 
-void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int nthreads, size_t lds_bytes,
-                     stream_t s) {
-  check_launch(ntiles, nthreads, lds_bytes);
-  if (even) {
-    ensure_lds(k_rows_r2c<true>, lds_bytes);
-    hipLaunchKernelGGL(k_rows_r2c<true>, dim3((unsigned)ntiles), dim3(nthreads), lds_bytes, hs(s), p);
-  } else {
-    ensure_lds(k_rows_r2c<false>, lds_bytes);
-    hipLaunchKernelGGL(k_rows_r2c<false>, dim3((unsigned)ntiles), dim3(nthreads), lds_bytes, hs(s), p);
-  }
+template <typename K, typename P>
+static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t lds_bytes, stream_t s) {
+  ensure_lds(kernel, lds_bytes);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(nthreads), lds_bytes, hs(s), p);
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int nthreads, size_t lds_bytes,
-                     stream_t s) {
-  check_launch(ntiles, nthreads, lds_bytes);
-  if (even) {
-    ensure_lds(k_rows_c2r<true>, lds_bytes);
-    hipLaunchKernelGGL(k_rows_c2r<true>, dim3((unsigned)ntiles), dim3(nthreads), lds_bytes, hs(s), p);
-  } else {
-    ensure_lds(k_rows_c2r<false>, lds_bytes);
-    hipLaunchKernelGGL(k_rows_c2r<false>, dim3((unsigned)ntiles), dim3(nthreads), lds_bytes, hs(s), p);
+#define MVN_DISPATCH_T(T_, KERNEL_EXPR)                                        \
+  switch (T_) {                                                                \
+    case 16: { constexpr int TT = 16; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break; \
+    case 8: { constexpr int TT = 8; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break;   \
+    case 4: { constexpr int TT = 4; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break;   \
+    case 2: { constexpr int TT = 2; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break;   \
+    case 1: { constexpr int TT = 1; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break;   \
+    default: throw std::invalid_argument("mvn: unsupported tile width");       \
   }
-  HIP_CHECK(hipGetLastError());
+
+void launch_rows_r2c(const RowsParams& p, bool even, long nblocks, int nthreads, size_t lds_bytes,
+                     stream_t s) {
+  check_launch(nblocks, nthreads, lds_bytes);
+  if (even) {
+    MVN_DISPATCH_T(p.T, (k_rows_r2c<true, TT>));
+  } else {
+    MVN_DISPATCH_T(p.T, (k_rows_r2c<false, TT>));
+  }
+}
+
+void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads, size_t lds_bytes,
+                     stream_t s) {
+  check_launch(nblocks, nthreads, lds_bytes);
+  if (even) {
+    MVN_DISPATCH_T(p.T, (k_rows_c2r<true, TT>));
+  } else {
+    MVN_DISPATCH_T(p.T, (k_rows_c2r<false, TT>));
+  }
 }
 
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
                     size_t lds_bytes, stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
-  const dim3 g((unsigned)nblocks), b(nthreads);
   switch (mode) {
-    case MVN_ST_FWD:
-      ensure_lds(k_strided<MVN_ST_FWD>, lds_bytes);
-      hipLaunchKernelGGL(k_strided<MVN_ST_FWD>, g, b, lds_bytes, hs(s), p);
-      break;
-    case MVN_ST_INV:
-      ensure_lds(k_strided<MVN_ST_INV>, lds_bytes);
-      hipLaunchKernelGGL(k_strided<MVN_ST_INV>, g, b, lds_bytes, hs(s), p);
-      break;
-    case MVN_ST_FWD_MUL_INV:
-      ensure_lds(k_strided<MVN_ST_FWD_MUL_INV>, lds_bytes);
-      hipLaunchKernelGGL(k_strided<MVN_ST_FWD_MUL_INV>, g, b, lds_bytes, hs(s), p);
-      break;
+    case MVN_ST_FWD: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD, TT>)); break;
+    case MVN_ST_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_INV, TT>)); break;
+    case MVN_ST_FWD_MUL_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD_MUL_INV, TT>)); break;
     default: throw std::invalid_argument("mvn: unknown strided mode");
   }
-  HIP_CHECK(hipGetLastError());
 }
 
 static unsigned flat_grid(size_t n, int block) {

@@ -103,6 +103,8 @@ struct RowsParams {
   long rows;          // d0*d1
   int T, TP;
   long lds_alt;       // offset (in cfloat) of the second LDS buffer, 0 if none
+  long lds_tw;        // offset (in cfloat) of the LDS twiddle copy
+  unsigned hmul, Cmul;  // mvn_fastdiv multipliers for h and C
   // r2c: real rows in (pitch RP floats) -> complex rows out (pitch C) + Nyquist plane
   const float* in_real;
   cfloat* out_cplx;
@@ -116,20 +118,22 @@ struct RowsParams {
 
 // real -> half-complex, even d2: z[j] = x[2j] + i x[2j+1], Z = FFT_h(z), then
 // X[k] = E - i w^k D,  E = (Z[k] + conj Z[h-k])/2,  D = (Z[k] - conj Z[h-k])/2,  w = exp(-2 pi i/d2)
+template <int T>
 MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
-  const int h = P.h, T = P.T, TP = P.TP;
+  const int h = P.h, TP = P.TP;
   const long r0 = tile * T;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
+  const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
   for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = w / h, j = w - rho * h;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
     const long row = r0 + rho;
     cfloat v = cmake(0.f, 0.f);
     if (row < P.rows) v = reinterpret_cast<const cfloat*>(P.in_real + row * P.RP)[j];
     buf[j * TP + rho] = v;
   }
   MVN_SYNC();
-  lds_fft_dif<-1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
   const int npairs = h / 2 + 1;
   for (int w = tid; w < npairs * T; w += nthreads) {
     const int k = w / T, rho = w - k * T;
@@ -150,7 +154,7 @@ MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthr
   }
   MVN_SYNC();
   for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = w / h, k = w - rho * h;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), k = w - rho * h;
     const long row = r0 + rho;
     if (row < P.rows) P.out_cplx[row * P.C + k] = buf[P.ax.inv[k] * TP + rho];
   }
@@ -158,13 +162,15 @@ MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthr
 
 // half-complex -> real, even d2: Z[k] = E + i O, E = X[k] + conj X[h-k],
 // O = (X[k] - conj X[h-k]) exp(+2 pi i k/d2); z = IFFT_h(Z); x[2j] = Re z[j], x[2j+1] = Im z[j]
+template <int T>
 MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
-  const int h = P.h, T = P.T, TP = P.TP;
+  const int h = P.h, TP = P.TP;
   const long r0 = tile * T;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
+  const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
   for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = w / h, k = w - rho * h;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), k = w - rho * h;
     const long row = r0 + rho;
     cfloat v = cmake(0.f, 0.f);
     if (row < P.rows) v = P.in_cplx[row * P.C + k];
@@ -192,9 +198,9 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
     }
   }
   MVN_SYNC();
-  lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
   for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = w / h, j = w - rho * h;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
     const long row = r0 + rho;
     if (row < P.rows) {
       const cfloat z = buf[j * TP + rho];
@@ -206,34 +212,38 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
 }
 
 // odd d2: plain complex transform of the real row, first C = (d2+1)/2 bins kept
+template <int T>
 MVN_HD void rows_r2c_odd_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
-  const int n = P.h, T = P.T, TP = P.TP;
+  const int n = P.h, TP = P.TP;
   const long r0 = tile * T;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
+  const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
   for (int w = tid; w < T * n; w += nthreads) {
-    const int rho = w / n, j = w - rho * n;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)n, P.hmul), j = w - rho * n;
     const long row = r0 + rho;
     float v = 0.f;
     if (row < P.rows) v = P.in_real[row * P.RP + j];
     buf[j * TP + rho] = cmake(v, 0.f);
   }
   MVN_SYNC();
-  lds_fft_dif<-1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
   for (int w = tid; w < T * P.C; w += nthreads) {
-    const int rho = w / P.C, k = w - rho * P.C;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)P.C, P.Cmul), k = w - rho * P.C;
     const long row = r0 + rho;
     if (row < P.rows) P.out_cplx[row * P.C + k] = buf[P.ax.inv[k] * TP + rho];
   }
 }
 
+template <int T>
 MVN_HD void rows_c2r_odd_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
-  const int n = P.h, T = P.T, TP = P.TP;
+  const int n = P.h, TP = P.TP;
   const long r0 = tile * T;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
+  const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
   for (int w = tid; w < T * n; w += nthreads) {
-    const int rho = w / n, k = w - rho * n;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)n, P.hmul), k = w - rho * n;
     const long row = r0 + rho;
     cfloat v = cmake(0.f, 0.f);
     if (row < P.rows) {
@@ -247,9 +257,9 @@ MVN_HD void rows_c2r_odd_body(const RowsParams& P, long tile, int tid, int nthre
     buf[P.ax.inv[k] * TP + rho] = v;
   }
   MVN_SYNC();
-  lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+  lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
   for (int w = tid; w < T * n; w += nthreads) {
-    const int rho = w / n, j = w - rho * n;
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)n, P.hmul), j = w - rho * n;
     const long row = r0 + rho;
     if (row < P.rows) mvn_epilogue(P.epi, P.out_real, row * P.RP + j, buf[j * TP + rho].x);
   }
@@ -273,11 +283,12 @@ struct StridedParams {
   int tiles_per_outer;
   int T, TP;
   long lds_alt;
+  long lds_tw;  // offset (in cfloat) of the LDS twiddle copy
 };
 
-template <int MODE>
+template <int MODE, int T>
 MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthreads, cfloat* lds) {
-  const int n = P.ax.n, T = P.T, TP = P.TP;
+  const int n = P.ax.n, TP = P.TP;
   const long o = block / P.tiles_per_outer;
   const int t = (int)(block - o * P.tiles_per_outer);
   const int c0 = t * T;
@@ -285,8 +296,9 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
   const long base = o * P.ostride + (long)c0 * P.cstride;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
+  const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
   for (int w = tid; w < n * T; w += nthreads) {
-    const int j = w / T, c = w - j * T;
+    const int j = w / T, c = w % T;
     cfloat v = cmake(0.f, 0.f);
     if (c < ncol) v = P.data[base + (long)j * P.estride + (long)c * P.cstride];
     const int pos = (MODE == MVN_ST_INV) ? P.ax.inv[j] : j;
@@ -294,23 +306,23 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
   }
   MVN_SYNC();
   if (MODE == MVN_ST_INV) {
-    lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+    lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
   } else {
-    lds_fft_dif<-1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+    lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
     if (MODE == MVN_ST_FWD_MUL_INV) {
       for (int w = tid; w < n * T; w += nthreads) {
-        const int p = w / T, c = w - p * T;
+        const int p = w / T, c = w % T;
         if (c < ncol) {
           const cfloat g = P.spec[base + (long)P.ax.rev[p] * P.estride + (long)c * P.cstride];
           buf[p * TP + c] = cmul(buf[p * TP + c], g);
         }
       }
       MVN_SYNC();
-      lds_fft_dit<+1>(buf, alt, TP, T, P.ax, P.ax.tw, tid, nthreads);
+      lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
     }
   }
   for (int w = tid; w < n * T; w += nthreads) {
-    const int p = w / T, c = w - p * T;
+    const int p = w / T, c = w % T;
     if (c < ncol) {
       const int row = (MODE == MVN_ST_FWD) ? P.ax.rev[p] : p;
       P.data[base + (long)row * P.estride + (long)c * P.cstride] = buf[p * TP + c];

@@ -89,7 +89,9 @@ struct AxisPlanHost {
     for (int s = 0; s < MVN_MAX_STAGES; ++s) {
       a.radix[s] = s < a.nstages ? radix[s] : 1;
       a.M[s] = s < a.nstages ? M[s] : 1;
+      a.Mmul[s] = mvn_fastdiv_mul((unsigned)a.M[s]);
     }
+    a.nmul = mvn_fastdiv_mul((unsigned)n);
     a.tw = tw_p;
     a.rev = rev_p;
     a.inv = inv_p;

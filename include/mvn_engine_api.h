@@ -37,6 +37,9 @@ MVN_API int mvn_fft3_c2r(int device, const int dims[3], const float* spec, float
 /* times `reps` forward (direction 0) or backward (1) transforms of a resident volume with
  * stream events; returns average milliseconds per transform in *ms */
 MVN_API int mvn_fft3_time(int device, const int dims[3], int direction, int reps, float* ms);
+/* same, plus the average launch time of every kernel kind (array of mvn_kernel_kind_count()) */
+MVN_API int mvn_fft3_profile(int device, const int dims[3], int direction, int reps, float* ms,
+                             double* per_kind_ms);
 
 /* ---- resident RL engine ----------------------------------------------------------------- */
 MVN_API int mvn_engine_create(int device, const int dims[3], int num_views, mvn_engine** out);

@@ -445,7 +445,12 @@ int mvn_fft3_c2r(int device, const int dims[3], const float* spec, float* real) 
 }
 
 int mvn_fft3_time(int device, const int dims[3], int direction, int reps, float* ms) {
-  return guarded("mvn_fft3_time", [&] {
+  return mvn_fft3_profile(device, dims, direction, reps, ms, nullptr);
+}
+
+int mvn_fft3_profile(int device, const int dims[3], int direction, int reps, float* ms,
+                     double* per_kind_ms) {
+  return guarded("mvn_fft3_profile", [&] {
     if (reps < 1) throw std::invalid_argument("reps must be >= 1");
     const int dev = pick_device(device);
     std::lock_guard<std::mutex> lk(device_mutex(dev));
@@ -477,6 +482,20 @@ int mvn_fft3_time(int device, const int dims[3], int direction, int reps, float*
     *ms = be::event_elapsed_ms(a, b) / (float)reps;
     be::event_destroy(a);
     be::event_destroy(b);
+    if (per_kind_ms) {  // second, event-instrumented round: average launch time per kernel kind
+      Profiler prof;
+      prof.enabled = true;
+      for (int i = 0; i < reps; ++i) {
+        if (direction == 0)
+          f.plan->forward(f.vol, f.nyq, f.s, &prof);
+        else
+          f.plan->backward(f.vol, f.nyq, keep, f.s, &prof);
+      }
+      be::stream_sync(f.s);
+      prof.collect();
+      for (int k = 0; k < KK_COUNT; ++k)
+        per_kind_ms[k] = prof.count[k] ? prof.total_ms[k] / (double)prof.count[k] : 0.0;
+    }
   });
 }
 

@@ -103,7 +103,14 @@ DevAxis::~DevAxis() {
   be::dfree(inv);
 }
 
-PassGeom Plan3D::pick_geom(int n, bool generic, bool rows) {
+// tuning knobs for experiments (not part of the ABI): MVN_T_ROWS / MVN_T_AXIS / MVN_T_FUSED cap
+// the tile width of the three pass families, MVN_THREADS fixes the workgroup size
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
+}
+
+PassGeom Plan3D::pick_geom(int n, bool generic, bool rows, int max_t) {
   static const int cand[5] = {16, 8, 4, 2, 1};
   PassGeom g;
   bool found = false;
@@ -111,6 +118,7 @@ PassGeom Plan3D::pick_geom(int n, bool generic, bool rows) {
     const size_t budget = pass == 0 ? kLdsSoftBudget : kLdsHardBudget;
     for (int i = 0; i < 5; ++i) {
       const int T = cand[i];
+      if (T > max_t) continue;
       const int TP = rows ? (T | 1) : T;  // odd pitch keeps the row transpose conflict-free
       const size_t one = (size_t)n * (size_t)TP * sizeof(cfloat);
       const size_t twb = (size_t)n * sizeof(cfloat);  // LDS copy of the twiddle table
@@ -132,6 +140,8 @@ PassGeom Plan3D::pick_geom(int n, bool generic, bool rows) {
   // one radix-8 butterfly per thread and stage when the tile is big enough
   const long work = (long)n * g.T / 8;
   g.threads = work >= 512 ? 512 : (work >= 256 ? 256 : (work >= 128 ? 128 : 64));
+  const int forced = env_int("MVN_THREADS", 0);
+  if (forced >= 64 && forced <= 512 && forced % 64 == 0) g.threads = forced;
   return g;
 }
 
@@ -148,9 +158,12 @@ Plan3D::Plan3D(int dev, int d0, int d1, int d2)
     be::h2d(twr, roots.data(), sizeof(cfloat) * roots.size(), nullptr);
     be::stream_sync(nullptr);
   }
-  g_rows = pick_geom(L.h, ax2.host.generic, true);
-  g_ax1 = pick_geom(d1, ax1.host.generic, false);
-  g_ax0 = pick_geom(d0, ax0.host.generic, false);
+  g_rows = pick_geom(L.h, ax2.host.generic, true, env_int("MVN_T_ROWS", 16));
+  g_ax1 = pick_geom(d1, ax1.host.generic, false, env_int("MVN_T_AXIS", 16));
+  g_ax0 = pick_geom(d0, ax0.host.generic, false, env_int("MVN_T_AXIS", 16));
+  // the fused pass has its own geometry so that it can be tuned apart (measured on MI355X at
+  // 512^3: T=16 0.46 ms, T=8 0.63 ms)
+  g_ax0f = pick_geom(d0, ax0.host.generic, false, env_int("MVN_T_FUSED", 16));
   g_nyq1 = g_ax1;
   g_nyq0 = g_ax0;
 }
@@ -238,6 +251,7 @@ void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler
   if (L.even) {
     // Nyquist plane [d0][d1]: lines along d1 are contiguous, neighbouring lines d1 apart
     StridedParams p = make_strided(ax1, g_nyq1, nyq, nullptr, 0, 1, L.d1, L.d0);
+    p.is_nyq = 1;
     ProfScope ps(prof, KK_NYQ, s);
     be::launch_strided(mode, p, p.tiles_per_outer, g_nyq1.threads, g_nyq1.lds_bytes, s);
   }
@@ -251,12 +265,14 @@ void Plan3D::axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec,
     // main array viewed as [d0][d1*C]: lines along d0, all (d1, bin) columns are contiguous
     const long cols = (long)L.d1 * L.C;
     if (cols > 0x7fffffffL) throw std::invalid_argument("mvn: d1*d2 too large");
-    StridedParams p = make_strided(ax0, g_ax0, data, spec, 0, cols, 1, (int)cols);
+    const PassGeom& g = mode == MVN_ST_FWD_MUL_INV ? g_ax0f : g_ax0;
+    StridedParams p = make_strided(ax0, g, data, spec, 0, cols, 1, (int)cols);
     ProfScope ps(prof, kind, s);
-    be::launch_strided(mode, p, p.tiles_per_outer, g_ax0.threads, g_ax0.lds_bytes, s);
+    be::launch_strided(mode, p, p.tiles_per_outer, g.threads, g.lds_bytes, s);
   }
   if (L.even) {
     StridedParams p = make_strided(ax0, g_nyq0, nyq, spec_nyq, 0, L.d1, 1, L.d1);
+    p.is_nyq = 1;
     ProfScope ps(prof, KK_NYQ, s);
     be::launch_strided(mode, p, p.tiles_per_outer, g_nyq0.threads, g_nyq0.lds_bytes, s);
   }

@@ -85,7 +85,7 @@ class Plan3D {
   const Layout L;
   DevAxis ax2, ax1, ax0;
   cfloat* twr = nullptr;  // d2-th roots of unity (even d2)
-  PassGeom g_rows, g_ax1, g_ax0, g_nyq1, g_nyq0;
+  PassGeom g_rows, g_ax1, g_ax0, g_ax0f, g_nyq1, g_nyq0;
 
   Plan3D(int device, int d0, int d1, int d2);
   ~Plan3D();
@@ -116,7 +116,7 @@ class Plan3D {
                     cfloat* spec_nyq, be::stream_t s) const;
 
  private:
-  static PassGeom pick_geom(int n, bool generic, bool rows);
+  static PassGeom pick_geom(int n, bool generic, bool rows, int max_t);
 };
 
 // Process-wide plan cache keyed by (device, logical shape); the reference keys by logical shape

@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(512) k_rows_c2r(const RowsParams p) {
     rows_c2r_odd_body<T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
 }
 
-template <int MODE, int T>
+// NYQ only tags the launches that work on the Nyquist plane, so that profilers list them apart
+template <int MODE, int T, bool NYQ>
 __global__ void __launch_bounds__(512) k_strided(const StridedParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   strided_body<MODE, T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
@@ -268,10 +269,19 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
                     size_t lds_bytes, stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (p.is_nyq) {
+    switch (mode) {
+      case MVN_ST_FWD: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD, TT, true>)); break;
+      case MVN_ST_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_INV, TT, true>)); break;
+      case MVN_ST_FWD_MUL_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD_MUL_INV, TT, true>)); break;
+      default: throw std::invalid_argument("mvn: unknown strided mode");
+    }
+    return;
+  }
   switch (mode) {
-    case MVN_ST_FWD: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD, TT>)); break;
-    case MVN_ST_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_INV, TT>)); break;
-    case MVN_ST_FWD_MUL_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD_MUL_INV, TT>)); break;
+    case MVN_ST_FWD: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD, TT, false>)); break;
+    case MVN_ST_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_INV, TT, false>)); break;
+    case MVN_ST_FWD_MUL_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD_MUL_INV, TT, false>)); break;
     default: throw std::invalid_argument("mvn: unknown strided mode");
   }
 }

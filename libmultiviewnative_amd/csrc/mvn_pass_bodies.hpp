@@ -92,6 +92,52 @@ MVN_HD void mvn_epilogue(const EpilogueParams& e, float* out, long i, float x) {
   }
 }
 
+// Pair form used by the even-d2 c2r pass: elements i, i+1 (i even, so 8-byte aligned) come out
+// of one complex LDS word.  Operands are fetched separately from the arithmetic so that the
+// fetch can be issued a whole transform ahead of its use; the (uniform) mode branch sits outside
+// the unrolled loops so that every branch is straight-line code with all its loads in flight.
+template <int U>
+MVN_HD void mvn_epilogue_fetch_batch(const EpilogueParams& e, const long* idx, cfloat* a, cfloat* b) {
+  if (e.mode == MVN_EPI_DIVIDE) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const cfloat*>(e.view + idx[u]);
+  } else if (e.mode == MVN_EPI_UPDATE || e.mode == MVN_EPI_DELTA) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const cfloat*>(e.psi + idx[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const cfloat*>(e.weights + idx[u]);
+  }
+}
+
+MVN_HD void mvn_epilogue_pair(const EpilogueParams& e, float* out, long i, cfloat z, cfloat a,
+                              cfloat b) {
+  MVN_FP_EXACT
+  const float x0 = z.x * e.scale, x1 = z.y * e.scale;
+  switch (e.mode) {
+    case MVN_EPI_STORE: *reinterpret_cast<cfloat*>(out + i) = cmake(x0, x1); break;
+    case MVN_EPI_DIVIDE:
+      *reinterpret_cast<cfloat*>(out + i) = cmake(mvn_quotient(a.x, x0), mvn_quotient(a.y, x1));
+      break;
+    case MVN_EPI_UPDATE: {
+      const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);
+      const float n1 = mvn_next_value(a.y, x1, e.lambda, e.lambda_inv, e.min_value);
+      *reinterpret_cast<cfloat*>(e.psi + i) = cmake(b.x * (n0 - a.x) + a.x, b.y * (n1 - a.y) + a.y);
+    } break;
+    case MVN_EPI_DELTA: {
+      const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);
+      const float n1 = mvn_next_value(a.y, x1, e.lambda, e.lambda_inv, e.min_value);
+      cfloat d = cmake(b.x * (n0 - a.x), b.y * (n1 - a.y));
+      if (e.accumulate) {
+        const cfloat old = *reinterpret_cast<const cfloat*>(e.delta + i);
+        d = cmake(old.x + d.x, old.y + d.y);
+      }
+      *reinterpret_cast<cfloat*>(e.delta + i) = d;
+    } break;
+  }
+}
+
+#define MVN_ROWS_U 8
+
 // ---------------------------------------------------------------------------------------------
 // last-axis passes (contiguous rows).  A tile is T rows; LDS holds them transposed,
 // lds[pos * TP + row], TP odd to keep the transposing accesses conflict-free.
@@ -125,12 +171,29 @@ MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthr
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
   const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
-  for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
-    const long row = r0 + rho;
-    cfloat v = cmake(0.f, 0.f);
-    if (row < P.rows) v = reinterpret_cast<const cfloat*>(P.in_real + row * P.RP)[j];
-    buf[j * TP + rho] = v;
+  constexpr int U = MVN_ROWS_U;
+  const int total = T * h;
+  const long last_row = P.rows - 1;
+  for (int w0 = tid; w0 < total; w0 += U * nthreads) {
+    cfloat v[U];
+    // every load is unconditional (clamped address) so that all U are in flight together
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int w = w0 + u * nthreads;
+      w = w < total ? w : total - 1;
+      const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
+      long row = r0 + rho;
+      row = row < last_row ? row : last_row;
+      v[u] = reinterpret_cast<const cfloat*>(P.in_real + row * P.RP)[j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w = w0 + u * nthreads;
+      if (w < total) {
+        const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
+        buf[j * TP + rho] = (r0 + rho <= last_row) ? v[u] : cmake(0.f, 0.f);
+      }
+    }
   }
   MVN_SYNC();
   lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
@@ -164,17 +227,44 @@ MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthr
 // O = (X[k] - conj X[h-k]) exp(+2 pi i k/d2); z = IFFT_h(Z); x[2j] = Re z[j], x[2j+1] = Im z[j]
 template <int T>
 MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
+  constexpr int U = MVN_ROWS_U;
   const int h = P.h, TP = P.TP;
   const long r0 = tile * T;
+  const int total = T * h;
+  const bool single = total <= U * nthreads;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
   const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
-  for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), k = w - rho * h;
-    const long row = r0 + rho;
-    cfloat v = cmake(0.f, 0.f);
-    if (row < P.rows) v = P.in_cplx[row * P.C + k];
-    buf[P.ax.inv[k] * TP + rho] = v;
+  cfloat ea[U], eb[U];  // epilogue operands, fetched a whole transform ahead when `single`
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    ea[u] = cmake(0.f, 0.f);
+    eb[u] = cmake(0.f, 0.f);
+  }
+  const long last_row = P.rows - 1;
+  for (int w0 = tid; w0 < total; w0 += U * nthreads) {
+    cfloat v[U];
+    long idx[U];
+    // unconditional, clamped loads: all U (and, if `single`, the epilogue operands) in flight
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int w = w0 + u * nthreads;
+      w = w < total ? w : total - 1;
+      const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), k = w - rho * h;
+      long row = r0 + rho;
+      row = row < last_row ? row : last_row;
+      v[u] = P.in_cplx[row * P.C + k];
+      idx[u] = row * P.RP + 2 * k;
+    }
+    if (single) mvn_epilogue_fetch_batch<U>(P.epi, idx, ea, eb);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w = w0 + u * nthreads;
+      if (w < total) {
+        const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), k = w - rho * h;
+        buf[P.ax.inv[k] * TP + rho] = (r0 + rho <= last_row) ? v[u] : cmake(0.f, 0.f);
+      }
+    }
   }
   MVN_SYNC();
   const int npairs = h / 2 + 1;
@@ -199,14 +289,27 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
   }
   MVN_SYNC();
   lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
-  for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
-    const long row = r0 + rho;
-    if (row < P.rows) {
-      const cfloat z = buf[j * TP + rho];
-      const long i = row * P.RP + 2 * j;
-      mvn_epilogue(P.epi, P.out_real, i, z.x);
-      mvn_epilogue(P.epi, P.out_real, i + 1, z.y);
+  for (int w0 = tid; w0 < total; w0 += U * nthreads) {
+    if (!single) {
+      long idx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int w = w0 + u * nthreads;
+        w = w < total ? w : total - 1;
+        const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
+        long row = r0 + rho;
+        row = row < last_row ? row : last_row;
+        idx[u] = row * P.RP + 2 * j;
+      }
+      mvn_epilogue_fetch_batch<U>(P.epi, idx, ea, eb);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w = w0 + u * nthreads;
+      const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
+      const long row = r0 + rho;
+      if (w < total && row <= last_row)
+        mvn_epilogue_pair(P.epi, P.out_real, row * P.RP + 2 * j, buf[j * TP + rho], ea[u], eb[u]);
     }
   }
 }
@@ -284,25 +387,59 @@ struct StridedParams {
   int T, TP;
   long lds_alt;
   long lds_tw;  // offset (in cfloat) of the LDS twiddle copy
+  int is_nyq;   // launch works on the Nyquist plane (profiling tag only)
 };
+
+// Loads are issued in batches of U per thread BEFORE any of them is consumed, so a tile's HBM
+// latency is paid once, not once per element.  When the whole tile is a single batch
+// (n*T <= U*nthreads, e.g. 512 x 16 on 512 threads) the fused mode also fetches its PSF-spectrum
+// operands up front and keeps them in registers across the forward transform.
+#define MVN_STRIDED_U 8
 
 template <int MODE, int T>
 MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthreads, cfloat* lds) {
+  constexpr int U = MVN_STRIDED_U;
   const int n = P.ax.n, TP = P.TP;
   const long o = block / P.tiles_per_outer;
   const int t = (int)(block - o * P.tiles_per_outer);
   const int c0 = t * T;
   const int ncol = (P.ncols - c0) < T ? (P.ncols - c0) : T;
   const long base = o * P.ostride + (long)c0 * P.cstride;
+  const int total = n * T;
+  const bool single = total <= U * nthreads;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
   const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
-  for (int w = tid; w < n * T; w += nthreads) {
-    const int j = w / T, c = w % T;
-    cfloat v = cmake(0.f, 0.f);
-    if (c < ncol) v = P.data[base + (long)j * P.estride + (long)c * P.cstride];
-    const int pos = (MODE == MVN_ST_INV) ? P.ax.inv[j] : j;
-    buf[pos * TP + c] = v;
+  cfloat g[U];
+  for (int w0 = tid; w0 < total; w0 += U * nthreads) {
+    cfloat v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int w = w0 + u * nthreads;
+      w = w < total ? w : total - 1;
+      int j = w / T, c = w % T;
+      c = c < ncol ? c : ncol - 1;  // clamped: the load itself is unconditional
+      v[u] = P.data[base + (long)j * P.estride + (long)c * P.cstride];
+    }
+    if (MODE == MVN_ST_FWD_MUL_INV && single) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int w = w0 + u * nthreads;
+        w = w < total ? w : total - 1;
+        int p = w / T, c = w % T;
+        c = c < ncol ? c : ncol - 1;
+        g[u] = P.spec[base + (long)P.ax.rev[p] * P.estride + (long)c * P.cstride];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w = w0 + u * nthreads;
+      if (w < total) {
+        const int j = w / T, c = w % T;
+        const int pos = (MODE == MVN_ST_INV) ? P.ax.inv[j] : j;
+        buf[pos * TP + c] = (c < ncol) ? v[u] : cmake(0.f, 0.f);
+      }
+    }
   }
   MVN_SYNC();
   if (MODE == MVN_ST_INV) {
@@ -310,18 +447,40 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
   } else {
     lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
     if (MODE == MVN_ST_FWD_MUL_INV) {
-      for (int w = tid; w < n * T; w += nthreads) {
-        const int p = w / T, c = w % T;
-        if (c < ncol) {
-          const cfloat g = P.spec[base + (long)P.ax.rev[p] * P.estride + (long)c * P.cstride];
-          buf[p * TP + c] = cmul(buf[p * TP + c], g);
+      if (single) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int w = tid + u * nthreads;
+          if (w < total) {
+            const int p = w / T, c = w % T;
+            buf[p * TP + c] = cmul(buf[p * TP + c], g[u]);
+          }
+        }
+      } else {
+        for (int w0 = tid; w0 < total; w0 += U * nthreads) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            int w = w0 + u * nthreads;
+            w = w < total ? w : total - 1;
+            int p = w / T, c = w % T;
+            c = c < ncol ? c : ncol - 1;
+            g[u] = P.spec[base + (long)P.ax.rev[p] * P.estride + (long)c * P.cstride];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int w = w0 + u * nthreads;
+            if (w < total) {
+              const int p = w / T, c = w % T;
+              buf[p * TP + c] = cmul(buf[p * TP + c], g[u]);
+            }
+          }
         }
       }
       MVN_SYNC();
       lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
     }
   }
-  for (int w = tid; w < n * T; w += nthreads) {
+  for (int w = tid; w < total; w += nthreads) {
     const int p = w / T, c = w % T;
     if (c < ncol) {
       const int row = (MODE == MVN_ST_FWD) ? P.ax.rev[p] : p;

@@ -29,7 +29,7 @@ REFERENCE_ABI_SYMBOLS = [
 ENGINE_ABI_SYMBOLS = [
     "mvn_last_error", "mvn_backend_name", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
-    "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_engine_create", "mvn_engine_destroy",
+    "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
     "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
     "mvn_engine_bind_delta", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
@@ -82,6 +82,8 @@ class Binding:
         l.mvn_fft3_r2c.argtypes = [C.c_int, i3, c_float_p, c_float_p]
         l.mvn_fft3_c2r.argtypes = [C.c_int, i3, c_float_p, c_float_p]
         l.mvn_fft3_time.argtypes = [C.c_int, i3, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        l.mvn_fft3_profile.argtypes = [C.c_int, i3, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                       C.POINTER(C.c_double)]
         l.mvn_engine_create.argtypes = [C.c_int, i3, C.c_int, C.POINTER(C.c_void_p)]
         l.mvn_engine_destroy.argtypes = [C.c_void_p]
         l.mvn_engine_set_view.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, i3,
@@ -162,6 +164,13 @@ class Binding:
         ms = C.c_float(0)
         self.check(self.l.mvn_fft3_time(device, _dims(shape), direction, reps, C.byref(ms)))
         return ms.value
+
+    def fft3_profile(self, shape, direction=0, reps=10, device=0):
+        ms = C.c_float(0)
+        n = self.l.mvn_kernel_kind_count()
+        per = (C.c_double * n)()
+        self.check(self.l.mvn_fft3_profile(device, _dims(shape), direction, reps, C.byref(ms), per))
+        return ms.value, {self.l.mvn_kernel_kind_name(k).decode(): per[k] for k in range(n) if per[k] > 0}
 
     def plan_describe(self, shape, device=0):
         out = (C.c_int * 8)()

@@ -10,8 +10,9 @@ print("backend", lib.backend_name())
 for shape in [(256, 256, 256), (512, 512, 512)]:
     B = 4 * shape[0] * shape[1] * 2 * (shape[2] // 2 + 1)
     for d in (0, 1):
-        ms = lib.fft3_time(shape, d, 10)
-        print("fft3", shape, "dir", d, "%.3f ms" % ms, "%.0f GB/s (6B model)" % (6 * B / ms / 1e6))
+        ms, per = lib.fft3_profile(shape, d, 10)
+        print("fft3", shape, "dir", d, "%.3f ms" % ms, "%.0f GB/s (6B model)" % (6 * B / ms / 1e6),
+              {k: round(v, 4) for k, v in per.items()})
     V = 2
     eng = lib.engine(shape, V)
     rng = np.random.default_rng(0)

@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--psf", type=int, default=31)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel events in the timed region")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip ms_per_fft and the small parity case (keeps rocprof --stats averages clean)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,14 +247,14 @@ def main():
         }
     eng.close()
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_side:
         try:
             out["ms_per_fft"] = round(lib.fft3_time(shape, 0, 10, device=local_rank), 4)
             out["parity"] = small_parity(lib)
         except Exception as e:  # the headline number must survive a failing side measurement
             out["side_measurement_error"] = str(e)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(shape, args.psf, V)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(shape, args.psf, V)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

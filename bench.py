@@ -50,6 +50,9 @@ def kernel_bytes(kind, d0, d1, d2):
     return {
         "rows_r2c": vol + B,            # read real volume, write half-spectrum (+ Nyquist plane)
         "rows_c2r": B + 2.5 * vol,      # read spectrum, write volume; + view (divide) or psi+weights (update): mean 1.5
+        # c2r + pointwise + r2c in one pass: read spectrum, write spectrum, + view (divide) or
+        # psi + weights in, psi out (update): mean 2 volumes
+        "rows_fused": 2 * B + 2.0 * vol,
         "axis1_fwd": 2 * vol,
         "axis1_inv": 2 * vol,
         "axis0_fused": 3 * vol,         # read data, read PSF spectrum, write data

@@ -26,8 +26,9 @@ MVN_API int mvn_plan_store_has_key(int device, const int dims[3]); /* 1 / 0 */
 MVN_API int mvn_plan_store_size(void);
 MVN_API int mvn_plan_store_empty(void);
 MVN_API int mvn_plan_store_clear(void);
-/* layout facts of a shape: {h, C, RP, even, rows_T, ax1_T, ax0_T, n_stages(d2 axis)} */
-MVN_API int mvn_plan_describe(int device, const int dims[3], int out[8]);
+/* layout facts of a shape: {h, C, RP, even, rows_T, ax1_T, ax0_T, n_stages(d2 axis),
+ * fixed-length kernel used for the last-axis / dim1 / dim0 passes (1/0 each), reserved} */
+MVN_API int mvn_plan_describe(int device, const int dims[3], int out[12]);
 
 /* ---- whole 3-D transforms on host buffers (test/bench utility) --------------------------
  * real:  dense [d0][d1][d2] floats.  spec: [d0][d1][d2/2+1] complex64 in the FFTW/cuFFT

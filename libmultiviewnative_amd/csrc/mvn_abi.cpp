@@ -369,7 +369,7 @@ int mvn_plan_store_clear(void) {
   return guarded("mvn_plan_store_clear", [&] { PlanStore::get().clear(); });
 }
 
-int mvn_plan_describe(int device, const int dims[3], int out[8]) {
+int mvn_plan_describe(int device, const int dims[3], int out[12]) {
   return guarded("mvn_plan_describe", [&] {
     std::shared_ptr<Plan3D> p = PlanStore::get().add(pick_device(device), to_shape(dims));
     out[0] = p->L.h;
@@ -380,6 +380,10 @@ int mvn_plan_describe(int device, const int dims[3], int out[8]) {
     out[5] = p->g_ax1.T;
     out[6] = p->g_ax0.T;
     out[7] = p->ax2.view.nstages;
+    out[8] = p->fx_rows ? 1 : 0;
+    out[9] = p->fx_ax1 ? 1 : 0;
+    out[10] = p->fx_ax0 ? 1 : 0;
+    out[11] = 0;
   });
 }
 

@@ -45,6 +45,8 @@ stream_t stream_create();
 void stream_destroy(stream_t s);
 void stream_sync(stream_t s);
 
+// make every later operation on `s` wait for event `e` (recorded on another stream)
+void stream_wait_event(stream_t s, event_t e);
 event_t event_create();
 void event_destroy(event_t e);
 void event_record(event_t e, stream_t s);
@@ -56,6 +58,10 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int nthreads, 
                      stream_t s);
 void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int nthreads, size_t lds_bytes,
                      stream_t s);
+// fixed-length only: c2r + pointwise epilogue + r2c of the result in one pass (p.fixed must be 1;
+// reads p.in_cplx / p.in_nyq, writes p.out_cplx / p.out_nyq, UPDATE also writes epi.psi)
+void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int nthreads, size_t lds_bytes,
+                         stream_t s);
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
                     size_t lds_bytes, stream_t s);
 

@@ -12,10 +12,12 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <vector>
 
 #include "mvn_backend.hpp"
+#include "mvn_fixed_geom.hpp"
 
 namespace mvn {
 namespace be {
@@ -68,6 +70,7 @@ void dzero(void* d, size_t bytes, stream_t) { std::memset(d, 0, bytes); }
 stream_t stream_create() { return (stream_t)1; }
 void stream_destroy(stream_t) {}
 void stream_sync(stream_t) {}
+void stream_wait_event(stream_t, event_t) {}
 
 struct EmuEvent {
   std::chrono::steady_clock::time_point t;
@@ -90,8 +93,86 @@ float event_elapsed_ms(event_t a, event_t b) {
     default: throw std::invalid_argument("mvn: unsupported tile width"); \
   }
 
+// fixed-length kernels: every phase is run for all thread ids in turn (real thread mapping)
+template <int H>
+static void emu_rows_fused(const RowsParams& p, long ntiles) {
+  typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+#pragma omp parallel
+  {
+    std::vector<char> lds(sizeof(cfloat) * FxRowsCfg<H>::lds_cfloats + 64);
+    std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+    for (long t = 0; t < ntiles; ++t) fx_rows_c2r_r2c_body<H>(p, t, (cfloat*)lds.data(), *ctx);
+  }
+}
+
+void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int, size_t, stream_t) {
+  switch (p.h) {
+#define X(H) case H: emu_rows_fused<H>(p, ntiles); return;
+    MVN_FIXED_ROWS_LENGTHS(X)
+#undef X
+    default: throw std::invalid_argument("mvn: no fixed kernel");
+  }
+}
+
+template <int H>
+static void emu_rows_fixed(const RowsParams& p, long ntiles, bool r2c) {
+  typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+#pragma omp parallel
+  {
+    std::vector<char> lds(sizeof(cfloat) * FxRowsCfg<H>::lds_cfloats + 64);
+    std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+    for (long t = 0; t < ntiles; ++t) {
+      if (r2c)
+        fx_rows_r2c_body<H>(p, t, (cfloat*)lds.data(), *ctx);
+      else
+        fx_rows_c2r_body<H>(p, t, (cfloat*)lds.data(), *ctx);
+    }
+  }
+}
+
+template <int N>
+static void emu_strided_fixed(int mode, const StridedParams& p, long nblocks) {
+  typedef FxCtx<FxStridedRegs<N>, FxStridedCfg<N>::NT> Ctx;
+#pragma omp parallel
+  {
+    std::vector<char> lds(sizeof(cfloat) * FxStridedCfg<N>::lds_cfloats + 64);
+    std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+    for (long b = 0; b < nblocks; ++b) {
+      cfloat* l = (cfloat*)lds.data();
+      if (mode == MVN_ST_FWD) fx_strided_body<N, MVN_ST_FWD>(p, b, l, *ctx);
+      if (mode == MVN_ST_INV) fx_strided_body<N, MVN_ST_INV>(p, b, l, *ctx);
+      if (mode == MVN_ST_FWD_MUL_INV) fx_strided_body<N, MVN_ST_FWD_MUL_INV>(p, b, l, *ctx);
+    }
+  }
+}
+
+static bool emu_rows_fixed_dispatch(const RowsParams& p, long ntiles, bool r2c) {
+  switch (p.h) {
+#define X(H) case H: emu_rows_fixed<H>(p, ntiles, r2c); return true;
+    MVN_FIXED_ROWS_LENGTHS(X)
+#undef X
+    default: return false;
+  }
+}
+
+static bool emu_strided_fixed_dispatch(int mode, const StridedParams& p, long nblocks) {
+  switch (p.ax.n) {
+#define X(N) case N: emu_strided_fixed<N>(mode, p, nblocks); return true;
+    MVN_FIXED_STRIDED_LENGTHS(X)
+#undef X
+    default: return false;
+  }
+}
+
 void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
+  if (p.fixed) {
+    if (!emu_rows_fixed_dispatch(p, ntiles, true)) throw std::invalid_argument("mvn: no fixed kernel");
+    return;
+  }
 #pragma omp parallel
   {
     std::vector<char> lds(lds_bytes + 64);
@@ -109,6 +190,10 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t ld
 
 void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
+  if (p.fixed) {
+    if (!emu_rows_fixed_dispatch(p, ntiles, false)) throw std::invalid_argument("mvn: no fixed kernel");
+    return;
+  }
 #pragma omp parallel
   {
     std::vector<char> lds(lds_bytes + 64);
@@ -126,6 +211,10 @@ void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t ld
 
 void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t lds_bytes,
                     stream_t) {
+  if (p.fixed) {
+    if (!emu_strided_fixed_dispatch(mode, p, nblocks)) throw std::invalid_argument("mvn: no fixed kernel");
+    return;
+  }
 #pragma omp parallel
   {
     std::vector<char> lds(lds_bytes + 64);

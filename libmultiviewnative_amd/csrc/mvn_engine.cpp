@@ -1,6 +1,8 @@
 // mvn_engine.cpp -- see mvn_engine.hpp
 #include "mvn_engine.hpp"
 
+#include "mvn_fixed_geom.hpp"
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,9 +14,9 @@ static const size_t kLdsSoftBudget = 80 * 1024;   // two workgroups per CU (160 
 static const size_t kLdsHardBudget = 160 * 1024;  // one workgroup may own the whole CU
 
 const char* kernel_kind_name(int k) {
-  static const char* names[KK_COUNT] = {"rows_r2c",    "rows_c2r",  "axis1_fwd",
-                                        "axis1_inv",   "axis0_fused", "axis0_fwd",
-                                        "axis0_inv",   "nyquist",   "other"};
+  static const char* names[KK_COUNT] = {"rows_r2c",  "rows_c2r",    "rows_fused", "axis1_fwd",
+                                        "axis1_inv", "axis0_fused", "axis0_fwd",  "axis0_inv",
+                                        "nyquist",   "other"};
   return (k >= 0 && k < KK_COUNT) ? names[k] : "?";
 }
 
@@ -91,14 +93,19 @@ DevAxis::DevAxis(int n) : host(n) {
   rev = (int*)be::dmalloc(sizeof(int) * (size_t)n);
   inv = (int*)be::dmalloc(sizeof(int) * (size_t)n);
   be::h2d(tw, host.tw.data(), sizeof(cfloat) * (size_t)n, nullptr);
+  if (!host.tws.empty()) {
+    tws = (cfloat*)be::dmalloc(sizeof(cfloat) * host.tws.size());
+    be::h2d(tws, host.tws.data(), sizeof(cfloat) * host.tws.size(), nullptr);
+  }
   be::h2d(rev, host.rev.data(), sizeof(int) * (size_t)n, nullptr);
   be::h2d(inv, host.inv.data(), sizeof(int) * (size_t)n, nullptr);
   be::stream_sync(nullptr);
-  view = host.view(tw, rev, inv);
+  view = host.view(tw, rev, inv, tws);
 }
 
 DevAxis::~DevAxis() {
   be::dfree(tw);
+  be::dfree(tws);
   be::dfree(rev);
   be::dfree(inv);
 }
@@ -166,6 +173,29 @@ Plan3D::Plan3D(int dev, int d0, int d1, int d2)
   g_ax0f = pick_geom(d0, ax0.host.generic, false, env_int("MVN_T_FUSED", 16));
   g_nyq1 = g_ax1;
   g_nyq0 = g_ax0;
+  // fixed-length fast path: power-of-two line, full tiles, 16-byte aligned rows
+  if (env_int("MVN_NO_FIXED", 0) == 0) {
+    int T = 0, threads = 0;
+    size_t lds = 0;
+    if (L.even && fixed_rows_geom(L.h, &T, &threads, &lds) && L.rows % (size_t)T == 0) {
+      fx_rows = true;
+      gx_rows.T = T;
+      gx_rows.threads = threads;
+      gx_rows.lds_bytes = lds;
+    }
+    if (fixed_strided_geom(d1, &T, &threads, &lds) && L.C % T == 0) {
+      fx_ax1 = true;
+      gx_ax1.T = gx_ax1.TP = T;
+      gx_ax1.threads = threads;
+      gx_ax1.lds_bytes = lds;
+    }
+    if (fixed_strided_geom(d0, &T, &threads, &lds) && ((long)L.d1 * L.C) % T == 0) {
+      fx_ax0 = true;
+      gx_ax0.T = gx_ax0.TP = T;
+      gx_ax0.threads = threads;
+      gx_ax0.lds_bytes = lds;
+    }
+  }
 }
 
 Plan3D::~Plan3D() { be::dfree(twr); }
@@ -190,8 +220,14 @@ void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::st
   p.in_real = in_real;
   p.out_cplx = out;
   p.out_nyq = out_nyq;
-  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
   ProfScope ps(prof, KK_ROWS_R2C, s);
+  if (fx_rows) {
+    p.fixed = 1;
+    p.T = gx_rows.T;
+    be::launch_rows_r2c(p, true, (long)L.rows / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
+    return;
+  }
+  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
   be::launch_rows_r2c(p, L.even, ntiles, g_rows.threads, g_rows.lds_bytes, s);
 }
 
@@ -216,9 +252,38 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   p.in_nyq = in_nyq;
   p.out_real = out_real;
   p.epi = epi;
-  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
   ProfScope ps(prof, KK_ROWS_C2R, s);
+  if (fx_rows) {
+    p.fixed = 1;
+    p.T = gx_rows.T;
+    be::launch_rows_c2r(p, true, (long)L.rows / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
+    return;
+  }
+  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
   be::launch_rows_c2r(p, L.even, ntiles, g_rows.threads, g_rows.lds_bytes, s);
+}
+
+void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, be::stream_t s,
+                          Profiler* prof) const {
+  if (!fx_rows) throw std::logic_error("mvn: rows_c2r_r2c needs a fixed-length plan");
+  RowsParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.ax = ax2.view;
+  p.twr = twr;
+  p.d2 = L.d2;
+  p.h = L.h;
+  p.C = L.C;
+  p.RP = L.RP;
+  p.rows = (long)L.rows;
+  p.T = gx_rows.T;
+  p.fixed = 1;
+  p.in_cplx = data;
+  p.in_nyq = nyq;
+  p.out_cplx = data;
+  p.out_nyq = nyq;
+  p.epi = epi;
+  ProfScope ps(prof, KK_ROWS_FUSED, s);
+  be::launch_rows_c2r_r2c(p, (long)L.rows / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
 }
 
 static StridedParams make_strided(const DevAxis& ax, const PassGeom& g, cfloat* data,
@@ -241,40 +306,61 @@ static StridedParams make_strided(const DevAxis& ax, const PassGeom& g, cfloat* 
   return p;
 }
 
-void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof) const {
+void SideStream::create() {
+  s = be::stream_create();
+  fork = be::event_create();
+  join = be::event_create();
+}
+
+void SideStream::destroy() {
+  if (s) be::stream_destroy(s);
+  be::event_destroy(fork);
+  be::event_destroy(join);
+  s = nullptr;
+  fork = join = nullptr;
+}
+
+void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof,
+                   be::stream_t s_nyq) const {
+  if (!s_nyq) s_nyq = s;
   {
     // main array [d0][d1][C]: lines along d1, tiles of neighbouring bins
-    StridedParams p = make_strided(ax1, g_ax1, data, nullptr, (long)L.d1 * L.C, L.C, 1, L.C);
+    const PassGeom& g = fx_ax1 ? gx_ax1 : g_ax1;
+    StridedParams p = make_strided(ax1, g, data, nullptr, (long)L.d1 * L.C, L.C, 1, L.C);
+    p.fixed = fx_ax1 ? 1 : 0;
     ProfScope ps(prof, mode == MVN_ST_FWD ? KK_AXIS1_FWD : KK_AXIS1_INV, s);
-    be::launch_strided(mode, p, (long)L.d0 * p.tiles_per_outer, g_ax1.threads, g_ax1.lds_bytes, s);
+    be::launch_strided(mode, p, (long)L.d0 * p.tiles_per_outer, g.threads, g.lds_bytes, s);
   }
   if (L.even) {
     // Nyquist plane [d0][d1]: lines along d1 are contiguous, neighbouring lines d1 apart
     StridedParams p = make_strided(ax1, g_nyq1, nyq, nullptr, 0, 1, L.d1, L.d0);
     p.is_nyq = 1;
-    ProfScope ps(prof, KK_NYQ, s);
-    be::launch_strided(mode, p, p.tiles_per_outer, g_nyq1.threads, g_nyq1.lds_bytes, s);
+    ProfScope ps(s_nyq == s ? prof : nullptr, KK_NYQ, s_nyq);
+    be::launch_strided(mode, p, p.tiles_per_outer, g_nyq1.threads, g_nyq1.lds_bytes, s_nyq);
   }
 }
 
 void Plan3D::axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec,
-                   const cfloat* spec_nyq, be::stream_t s, Profiler* prof) const {
+                   const cfloat* spec_nyq, be::stream_t s, Profiler* prof,
+                   be::stream_t s_nyq) const {
+  if (!s_nyq) s_nyq = s;
   const int kind = mode == MVN_ST_FWD ? KK_AXIS0_FWD
                                       : (mode == MVN_ST_INV ? KK_AXIS0_INV : KK_AXIS0_FUSED);
   {
     // main array viewed as [d0][d1*C]: lines along d0, all (d1, bin) columns are contiguous
     const long cols = (long)L.d1 * L.C;
     if (cols > 0x7fffffffL) throw std::invalid_argument("mvn: d1*d2 too large");
-    const PassGeom& g = mode == MVN_ST_FWD_MUL_INV ? g_ax0f : g_ax0;
+    const PassGeom& g = fx_ax0 ? gx_ax0 : (mode == MVN_ST_FWD_MUL_INV ? g_ax0f : g_ax0);
     StridedParams p = make_strided(ax0, g, data, spec, 0, cols, 1, (int)cols);
+    p.fixed = fx_ax0 ? 1 : 0;
     ProfScope ps(prof, kind, s);
     be::launch_strided(mode, p, p.tiles_per_outer, g.threads, g.lds_bytes, s);
   }
   if (L.even) {
     StridedParams p = make_strided(ax0, g_nyq0, nyq, spec_nyq, 0, L.d1, 1, L.d1);
     p.is_nyq = 1;
-    ProfScope ps(prof, KK_NYQ, s);
-    be::launch_strided(mode, p, p.tiles_per_outer, g_nyq0.threads, g_nyq0.lds_bytes, s);
+    ProfScope ps(s_nyq == s ? prof : nullptr, KK_NYQ, s_nyq);
+    be::launch_strided(mode, p, p.tiles_per_outer, g_nyq0.threads, g_nyq0.lds_bytes, s_nyq);
   }
 }
 
@@ -293,6 +379,26 @@ void Plan3D::backward(float* vol, cfloat* nyq, float scale, be::stream_t s,
   e.mode = MVN_EPI_STORE;
   e.scale = scale;
   rows_c2r((const cfloat*)vol, nyq, vol, e, s, prof);
+}
+
+void Plan3D::middle_passes(cfloat* work, cfloat* work_nyq, const cfloat* spec,
+                           const cfloat* spec_nyq, be::stream_t s, Profiler* prof,
+                           SideStream* side) const {
+  be::stream_t sn = s;
+  if (side && side->s && L.even) {
+    // fork: the plane was written by the last-axis pass just enqueued on s
+    be::event_record(side->fork, s);
+    be::stream_wait_event(side->s, side->fork);
+    sn = side->s;
+  }
+  axis1(MVN_ST_FWD, work, work_nyq, s, prof, sn);
+  axis0(MVN_ST_FWD_MUL_INV, work, work_nyq, spec, spec_nyq, s, prof, sn);
+  axis1(MVN_ST_INV, work, work_nyq, s, prof, sn);
+  if (sn != s) {
+    // join: the next last-axis pass on s reads the plane
+    be::event_record(side->join, sn);
+    be::stream_wait_event(s, side->join);
+  }
 }
 
 void Plan3D::convolve(const float* in_real, cfloat* work, cfloat* work_nyq, const cfloat* spec,
@@ -381,6 +487,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   be::set_device(device_);
   plan_ = PlanStore::get().add(device_, dims);
   stream_ = be::stream_create();
+  side_.create();
   const size_t mb = plan_->main_bytes();
   psi_ = (float*)be::dmalloc(mb);
   work_ = (float*)be::dmalloc(mb);
@@ -409,6 +516,11 @@ Engine::~Engine() {
   be::dfree(work_);
   be::dfree(work_nyq_);
   if (!delta_external_) be::dfree(delta_);
+  try {
+    if (side_.s) be::stream_sync(side_.s);
+  } catch (...) {
+  }
+  side_.destroy();
   if (stream_) be::stream_destroy(stream_);
 }
 
@@ -480,19 +592,27 @@ void Engine::get_psi(float* host) {
   be::stream_sync(stream_);
 }
 
-// one (view, iteration): the reference's steps 1-4, src/gpu_deconvolve_methods.cuh:491-532
-void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate) {
+// one (view, iteration): the reference's steps 1-4, src/gpu_deconvolve_methods.cuh:491-532.
+//   psi (*) kernel1 -> view / blurred -> (*) kernel2 -> psi update
+// With a fixed-length plan the two last-axis passes that meet between the convolutions
+// (c2r + divide, then r2c) run as ONE kernel, and so do the update pass and the forward
+// last-axis pass of the NEXT (view, iteration) when `feed_next` is set: 8 full passes instead of 10.
+void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate,
+                       bool feed_next) {
   const ViewSlot& s = views_[(size_t)v];
   if (!s.set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
   Profiler* prof = prof_.enabled ? &prof_ : nullptr;
+  const Plan3D& P = *plan_;
+  cfloat* W = (cfloat*)work_;
+  static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;  // A/B knob for experiments
+  const bool fuse = P.can_fuse_rows() && !no_fuse;
+
   EpilogueParams e1;
   std::memset(&e1, 0, sizeof(e1));
   e1.mode = MVN_EPI_DIVIDE;
   e1.scale = 1.f;  // 1/N already lives in the PSF spectrum
   e1.view = s.image;
-  // psi (*) kernel1, then view / blurred, written as the next convolution's input
-  plan_->convolve(psi_, (cfloat*)work_, work_nyq_, (const cfloat*)s.spec1, s.nyq1, work_, e1,
-                  stream_, prof);
+
   EpilogueParams e2;
   std::memset(&e2, 0, sizeof(e2));
   e2.mode = final_mode;
@@ -504,15 +624,40 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   e2.lambda = lambda;
   e2.lambda_inv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
   e2.min_value = min_value;
-  // quotient (*) kernel2, then the psi update fused into the last pass
-  plan_->convolve(work_, (cfloat*)work_, work_nyq_, (const cfloat*)s.spec2, s.nyq2, psi_, e2,
-                  stream_, prof);
+
+  // convolution 1: psi (*) kernel1
+  static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;  // A/B knob
+  SideStream* side = no_side ? nullptr : &side_;
+  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, W, work_nyq_, stream_, prof);
+  work_has_psi_spectrum_ = false;
+  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, side);
+  // view / blurred, handed to convolution 2 as its last-axis spectrum
+  if (fuse) {
+    P.rows_c2r_r2c(W, work_nyq_, e1, stream_, prof);
+  } else {
+    P.rows_c2r(W, work_nyq_, work_, e1, stream_, prof);
+    P.rows_r2c(work_, W, work_nyq_, stream_, prof);
+  }
+  // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
+  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof, side);
+  if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
+    P.rows_c2r_r2c(W, work_nyq_, e2, stream_, prof);
+    work_has_psi_spectrum_ = true;
+  } else {
+    P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
+  }
 }
 
 void Engine::iterate(int iterations, double lambda, float min_value) {
   be::set_device(device_);
+  work_has_psi_spectrum_ = false;  // psi may have been replaced since the last call
+  const int V = (int)views_.size();
   for (int it = 0; it < iterations; ++it)
-    for (int v = 0; v < (int)views_.size(); ++v) conv_pair(v, lambda, min_value, MVN_EPI_UPDATE, 0);
+    for (int v = 0; v < V; ++v) {
+      const bool last = (it == iterations - 1) && (v == V - 1);
+      conv_pair(v, lambda, min_value, MVN_EPI_UPDATE, 0, !last);
+    }
+  work_has_psi_spectrum_ = false;
 }
 
 float* Engine::delta_ptr() {
@@ -535,8 +680,9 @@ void Engine::bind_delta(float* external) {
 void Engine::compute_delta(double lambda, float min_value) {
   be::set_device(device_);
   delta_ptr();
+  work_has_psi_spectrum_ = false;
   for (int v = 0; v < (int)views_.size(); ++v)
-    conv_pair(v, lambda, min_value, MVN_EPI_DELTA, v == 0 ? 0 : 1);
+    conv_pair(v, lambda, min_value, MVN_EPI_DELTA, v == 0 ? 0 : 1, false);
 }
 
 void Engine::apply_delta() {

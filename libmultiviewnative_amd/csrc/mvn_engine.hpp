@@ -24,6 +24,7 @@ namespace mvn {
 enum KernelKind {
   KK_ROWS_R2C = 0,
   KK_ROWS_C2R,
+  KK_ROWS_FUSED,
   KK_AXIS1_FWD,
   KK_AXIS1_INV,
   KK_AXIS0_FUSED,
@@ -61,6 +62,7 @@ class Profiler {
 struct DevAxis {
   AxisPlanHost host;
   cfloat* tw = nullptr;
+  cfloat* tws = nullptr;
   int* rev = nullptr;
   int* inv = nullptr;
   AxisPlan view;
@@ -79,6 +81,14 @@ struct PassGeom {
 
 typedef std::array<int, 3> shape_t;
 
+// a second stream plus the two events used to fork it from / join it to the main stream
+struct SideStream {
+  be::stream_t s = nullptr;
+  be::event_t fork = nullptr, join = nullptr;
+  void create();
+  void destroy();
+};
+
 class Plan3D {
  public:
   const int device;
@@ -86,6 +96,9 @@ class Plan3D {
   DevAxis ax2, ax1, ax0;
   cfloat* twr = nullptr;  // d2-th roots of unity (even d2)
   PassGeom g_rows, g_ax1, g_ax0, g_ax0f, g_nyq1, g_nyq0;
+  // compile-time specialised kernels (mvn_fixed.hpp) are used where the shape allows
+  bool fx_rows = false, fx_ax1 = false, fx_ax0 = false;
+  PassGeom gx_rows, gx_ax1, gx_ax0;
 
   Plan3D(int device, int d0, int d1, int d2);
   ~Plan3D();
@@ -98,10 +111,18 @@ class Plan3D {
                 Profiler* prof = nullptr) const;
   void rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
                 const EpilogueParams& epi, be::stream_t s, Profiler* prof = nullptr) const;
+  // fused c2r + pointwise + r2c (fixed-length plans only, see can_fuse_rows()); in place on
+  // (data, nyq); epi.mode is DIVIDE, UPDATE or STORE
+  bool can_fuse_rows() const { return fx_rows; }
+  void rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, be::stream_t s,
+                    Profiler* prof = nullptr) const;
   // strided passes on the main array and its Nyquist plane; mode = MvnStridedMode
-  void axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr) const;
+  // `s_nyq` (default: s) is the stream of the small Nyquist-plane launches; giving them their own
+  // stream lets the 2 MB plane ride along with the full-volume passes (see SideStream)
+  void axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr,
+             be::stream_t s_nyq = nullptr) const;
   void axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec, const cfloat* spec_nyq,
-             be::stream_t s, Profiler* prof = nullptr) const;
+             be::stream_t s, Profiler* prof = nullptr, be::stream_t s_nyq = nullptr) const;
 
   // whole transforms, un-normalised, in place on (vol, nyq)
   void forward(float* vol, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr) const;
@@ -111,6 +132,11 @@ class Plan3D {
   void convolve(const float* in_real, cfloat* work, cfloat* work_nyq, const cfloat* spec,
                 const cfloat* spec_nyq, float* out_real, const EpilogueParams& epi,
                 be::stream_t s, Profiler* prof = nullptr) const;
+  // the three strided passes of a convolution (dim1 forward, dim0 forward*PSF*inverse, dim1
+  // inverse); with `side` the Nyquist plane's three launches run on a second stream, forked
+  // after and joined before the last-axis passes that produce / consume the plane
+  void middle_passes(cfloat* work, cfloat* work_nyq, const cfloat* spec, const cfloat* spec_nyq,
+                     be::stream_t s, Profiler* prof, struct SideStream* side) const;
   // spectrum of a PSF: zero volume, centre->origin wrapped insert scaled by `scale`, forward FFT
   void psf_spectrum(const float* d_kernel, const int* kdims, float scale, float* spec_vol,
                     cfloat* spec_nyq, be::stream_t s) const;
@@ -183,16 +209,19 @@ class Engine {
   void sync();
 
  private:
-  void conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate);
+  void conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate,
+                 bool feed_next);
   void upload_volume(float* dst, const float* host);
   int device_;
   std::shared_ptr<Plan3D> plan_;
   be::stream_t stream_ = nullptr;
+  SideStream side_;
   float* psi_ = nullptr;
   float* work_ = nullptr;
   cfloat* work_nyq_ = nullptr;
   float* delta_ = nullptr;
   bool delta_external_ = false;
+  bool work_has_psi_spectrum_ = false;  // work_ holds the last-axis transform of the current psi
   std::vector<ViewSlot> views_;
   Profiler prof_;
 };

@@ -49,6 +49,7 @@ struct AxisPlan {
   unsigned Mmul[MVN_MAX_STAGES];  // ceil(2^32 / M[s]): x / M[s] == umulhi(x, Mmul[s]) (mvn_fastdiv)
   unsigned nmul;                  // same for n
   const cfloat* tw;           // tw[j] = exp(-2 pi i j / n)
+  const cfloat* tws;          // stage-ordered twiddles of the fixed-length kernels (mvn_fixed.hpp)
   const int* rev;             // rev[p] = k : after DIF, position p holds X[k]
   const int* inv;             // inv[k] = p
 };

@@ -20,6 +20,7 @@
 #include <string>
 
 #include "mvn_backend.hpp"
+#include "mvn_fixed_geom.hpp"
 
 #define HIP_CHECK(expr)                                                                      \
   do {                                                                                       \
@@ -55,6 +56,39 @@ template <int MODE, int T, bool NYQ>
 __global__ void __launch_bounds__(512) k_strided(const StridedParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   strided_body<MODE, T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+}
+
+// ---- compile-time specialised kernels for power-of-two lengths (mvn_fixed.hpp) ----------------
+template <int H>
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_r2c(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  fx_rows_r2c_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+}
+
+template <int H>
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  fx_rows_c2r_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+}
+
+template <int H>
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  fx_rows_c2r_r2c_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+}
+
+template <int N, int MODE>
+__global__ void __launch_bounds__(FxStridedCfg<N>::NT) kx_strided(const StridedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<FxStridedRegs<N>, FxStridedCfg<N>::NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  fx_strided_body<N, MODE>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
 __global__ void k_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
@@ -198,6 +232,10 @@ void stream_destroy(stream_t s) {
 }
 void stream_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(hs(s))); }
 
+void stream_wait_event(stream_t s, event_t e) {
+  HIP_CHECK(hipStreamWaitEvent(hs(s), (hipEvent_t)e, 0));
+}
+
 event_t event_create() {
   hipEvent_t e;
   HIP_CHECK(hipEventCreate(&e));
@@ -229,13 +267,6 @@ static void check_launch(long nblocks, int nthreads, size_t lds_bytes) {
   if (lds_bytes > 160 * 1024) throw std::invalid_argument("mvn: LDS request exceeds 160 KiB");
 }
 
-template <typename K, typename P>
-static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t lds_bytes, stream_t s) {
-  ensure_lds(kernel, lds_bytes);
-  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(nthreads), lds_bytes, hs(s), p);
-  HIP_CHECK(hipGetLastError());
-}
-
 #define MVN_DISPATCH_T(T_, KERNEL_EXPR)                                        \
   switch (T_) {                                                                \
     case 16: { constexpr int TT = 16; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break; \
@@ -246,9 +277,30 @@ static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t
     default: throw std::invalid_argument("mvn: unsupported tile width");       \
   }
 
+template <typename K, typename P>
+static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t lds_bytes, stream_t s) {
+  ensure_lds(kernel, lds_bytes);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(nthreads), lds_bytes, hs(s), p);
+  HIP_CHECK(hipGetLastError());
+}
+
+static void check_aligned16(const void* p, const char* what) {
+  if (((size_t)p) & 15) throw std::invalid_argument(std::string("mvn: fixed kernels need 16-byte aligned ") + what);
+}
+
 void launch_rows_r2c(const RowsParams& p, bool even, long nblocks, int nthreads, size_t lds_bytes,
                      stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (p.fixed) {
+    check_aligned16(p.in_real, "input");
+    check_aligned16(p.out_cplx, "output");
+    switch (p.h) {
+#define X(H) case H: launch_pass(kx_rows_r2c<H>, p, nblocks, nthreads, lds_bytes, s); return;
+      MVN_FIXED_ROWS_LENGTHS(X)
+#undef X
+      default: throw std::invalid_argument("mvn: no fixed rows kernel for this length");
+    }
+  }
   if (even) {
     MVN_DISPATCH_T(p.T, (k_rows_r2c<true, TT>));
   } else {
@@ -259,6 +311,16 @@ void launch_rows_r2c(const RowsParams& p, bool even, long nblocks, int nthreads,
 void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads, size_t lds_bytes,
                      stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (p.fixed) {
+    check_aligned16(p.in_cplx, "input");
+    check_aligned16(p.out_real, "output");
+    switch (p.h) {
+#define X(H) case H: launch_pass(kx_rows_c2r<H>, p, nblocks, nthreads, lds_bytes, s); return;
+      MVN_FIXED_ROWS_LENGTHS(X)
+#undef X
+      default: throw std::invalid_argument("mvn: no fixed rows kernel for this length");
+    }
+  }
   if (even) {
     MVN_DISPATCH_T(p.T, (k_rows_c2r<true, TT>));
   } else {
@@ -266,9 +328,38 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
   }
 }
 
+void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t lds_bytes,
+                         stream_t s) {
+  check_launch(nblocks, nthreads, lds_bytes);
+  if (!p.fixed) throw std::invalid_argument("mvn: the fused rows pass exists for fixed lengths only");
+  check_aligned16(p.in_cplx, "input");
+  check_aligned16(p.out_cplx, "output");
+  switch (p.h) {
+#define X(H) case H: launch_pass(kx_rows_c2r_r2c<H>, p, nblocks, nthreads, lds_bytes, s); return;
+    MVN_FIXED_ROWS_LENGTHS(X)
+#undef X
+    default: throw std::invalid_argument("mvn: no fixed rows kernel for this length");
+  }
+}
+
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
                     size_t lds_bytes, stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (p.fixed) {
+    check_aligned16(p.data, "data");
+    if (mode == MVN_ST_FWD_MUL_INV) check_aligned16(p.spec, "spectrum");
+    switch (p.ax.n) {
+#define X(N)                                                                                       \
+  case N:                                                                                          \
+    if (mode == MVN_ST_FWD) launch_pass(kx_strided<N, MVN_ST_FWD>, p, nblocks, nthreads, lds_bytes, s); \
+    else if (mode == MVN_ST_INV) launch_pass(kx_strided<N, MVN_ST_INV>, p, nblocks, nthreads, lds_bytes, s); \
+    else launch_pass(kx_strided<N, MVN_ST_FWD_MUL_INV>, p, nblocks, nthreads, lds_bytes, s);       \
+    return;
+      MVN_FIXED_STRIDED_LENGTHS(X)
+#undef X
+      default: throw std::invalid_argument("mvn: no fixed strided kernel for this length");
+    }
+  }
   if (p.is_nyq) {
     switch (mode) {
       case MVN_ST_FWD: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD, TT, true>)); break;

@@ -47,10 +47,15 @@ struct EpilogueParams {
   float min_value;
 };
 
-// inc/cpu_kernels.h:22-25: TransferT temp = 1. / out; out = in * temp
+// inc/cpu_kernels.h:22-25: TransferT temp = 1. / out; out = in * temp, i.e. a DOUBLE divide
+// rounded to float.  Double carries 53 >= 2*24+2 bits, so that double rounding is innocuous and
+// float(1.0 / double(x)) is exactly the correctly rounded single-precision quotient 1.0f / x
+// (checked on 1e8 random bit patterns in tests/test_oracle_kernels.py).  hipcc divides floats
+// correctly rounded by default (-fhip-fp32-correctly-rounded-divide-sqrt), at a fraction of the
+// cost of the f64 sequence.
 MVN_HD float mvn_quotient(float view, float blurred) {
   MVN_FP_EXACT
-  float t = (float)(1.0 / (double)blurred);
+  float t = 1.0f / blurred;
   return view * t;
 }
 
@@ -151,6 +156,7 @@ struct RowsParams {
   long lds_alt;       // offset (in cfloat) of the second LDS buffer, 0 if none
   long lds_tw;        // offset (in cfloat) of the LDS twiddle copy
   unsigned hmul, Cmul;  // mvn_fastdiv multipliers for h and C
+  int fixed;            // 1: launch the compile-time specialised kernel for this h (mvn_fixed.hpp)
   // r2c: real rows in (pitch RP floats) -> complex rows out (pitch C) + Nyquist plane
   const float* in_real;
   cfloat* out_cplx;
@@ -388,6 +394,7 @@ struct StridedParams {
   long lds_alt;
   long lds_tw;  // offset (in cfloat) of the LDS twiddle copy
   int is_nyq;   // launch works on the Nyquist plane (profiling tag only)
+  int fixed;    // 1: launch the compile-time specialised kernel for this length (mvn_fixed.hpp)
 };
 
 // Loads are issued in batches of U per thread BEFORE any of them is consumed, so a tile's HBM

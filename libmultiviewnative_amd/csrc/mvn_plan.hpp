@@ -29,6 +29,7 @@ struct AxisPlanHost {
   std::vector<int> radix;  // DIF order
   std::vector<int> M;
   std::vector<cfloat> tw;
+  std::vector<cfloat> tws;  // per stage with M > 1: M rows of R entries exp(-2 pi i j2 k / (R M))
   std::vector<int> rev, inv;
   bool generic = false;
   int max_generic_radix = 0;
@@ -66,6 +67,18 @@ struct AxisPlanHost {
       tw[j].x = (float)std::cos(a);
       tw[j].y = (float)std::sin(a);
     }
+    for (size_t s = 0; s < radix.size(); ++s) {
+      if (M[s] <= 1) continue;
+      const int R = radix[s], L = R * M[s];
+      for (int j2 = 0; j2 < M[s]; ++j2)
+        for (int k = 0; k < R; ++k) {
+          double a = -2.0 * M_PI * (double)((long)j2 * k % L) / (double)L;
+          cfloat w;
+          w.x = (float)std::cos(a);
+          w.y = (float)std::sin(a);
+          tws.push_back(w);
+        }
+    }
     rev.resize(n);
     inv.resize(n);
     for (int p = 0; p < n; ++p) {
@@ -81,7 +94,8 @@ struct AxisPlanHost {
   }
 
   // kernel-visible plan; table pointers are filled by whoever owns the (device) copies
-  AxisPlan view(const cfloat* tw_p, const int* rev_p, const int* inv_p) const {
+  AxisPlan view(const cfloat* tw_p, const int* rev_p, const int* inv_p,
+                const cfloat* tws_p = nullptr) const {
     AxisPlan a;
     a.n = n;
     a.nstages = (int)radix.size();
@@ -93,6 +107,7 @@ struct AxisPlanHost {
     }
     a.nmul = mvn_fastdiv_mul((unsigned)n);
     a.tw = tw_p;
+    a.tws = tws_p;
     a.rev = rev_p;
     a.inv = inv_p;
     return a;

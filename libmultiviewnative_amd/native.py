@@ -173,9 +173,10 @@ class Binding:
         return ms.value, {self.l.mvn_kernel_kind_name(k).decode(): per[k] for k in range(n) if per[k] > 0}
 
     def plan_describe(self, shape, device=0):
-        out = (C.c_int * 8)()
+        out = (C.c_int * 12)()
         self.check(self.l.mvn_plan_describe(device, _dims(shape), out))
-        keys = ["h", "C", "RP", "even", "rows_T", "ax1_T", "ax0_T", "n_stages"]
+        keys = ["h", "C", "RP", "even", "rows_T", "ax1_T", "ax0_T", "n_stages", "fx_rows", "fx_ax1",
+                "fx_ax0", "reserved"]
         return dict(zip(keys, list(out)))
 
     def engine(self, shape, num_views, device=0):

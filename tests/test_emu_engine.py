@@ -25,6 +25,55 @@ SHAPES = [(8, 8, 8), (4, 6, 10), (13, 17, 19), (16, 18, 14), (6, 10, 15), (32, 2
           (12, 7, 9), (1, 1, 4), (2, 3, 1), (24, 40, 22), (64, 64, 64), (5, 4, 46)]
 
 
+# shapes that take the compile-time specialised kernels (mvn_fixed.hpp): (fx_rows, fx_ax1, fx_ax0)
+FIXED_SHAPES = {(64, 64, 64): (1, 1, 1), (64, 128, 256): (1, 1, 1), (128, 64, 512): (1, 1, 1),
+                (256, 64, 64): (1, 1, 1), (64, 512, 64): (1, 1, 1), (1024, 64, 32): (0, 1, 1),
+                (64, 64, 1024): (1, 1, 1), (8, 64, 2048): (1, 1, 0), (16, 1024, 64): (1, 1, 0),
+                (32, 20, 64): (1, 0, 0)}
+
+
+@pytest.mark.parametrize("shape", sorted(FIXED_SHAPES))
+def test_fixed_kernels_roundtrip_and_forward(emu, shape):
+    info = emu.plan_describe(shape)
+    assert (info["fx_rows"], info["fx_ax1"], info["fx_ax0"]) == FIXED_SHAPES[shape]
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = emu.rfft3(x)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
+    back = emu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 1e-5
+
+
+def test_fixed_kernels_deconvolve_vs_oracle(emu):
+    shape = (64, 64, 128)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 7, 9))
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 2)
+        got = emu.gpu_deconvolve(psi0, h)
+        ref = orc.cpu_deconvolve(psi0, h, 4)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+        assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-5 * np.sqrt(np.mean(ref ** 2))
+
+
+def test_fused_pipeline_invariants(emu):
+    # the 8-pass pipeline (c2r+divide+r2c and c2r+update+r2c fused) keeps the loop invariants:
+    # N iterations == N x 1 iteration bit for bit, and the last pass leaves psi complete
+    shape = (32, 32, 64)
+    assert emu.plan_describe(shape)["fx_rows"] == 1
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (5, 5, 5))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    three = emu.gpu_deconvolve(psi0, h)
+    h.with_iterations(1)
+    one = psi0
+    for _ in range(3):
+        one = emu.gpu_deconvolve(one, h)
+    assert np.array_equal(one, three)
+    h.with_iterations(3)
+    ref = orc.cpu_deconvolve(psi0, h, 4)
+    assert np.abs(three - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_forward_vs_pocketfft(emu, shape):
     rng = np.random.default_rng(7)

@@ -73,6 +73,62 @@ def test_backward_vs_pocketfft(gpu, shape):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
 
 
+# shapes served by the compile-time specialised kernels: expected (fx_rows, fx_ax1, fx_ax0)
+FIXED_SHAPES = {(64, 64, 64): (1, 1, 1), (64, 128, 256): (1, 1, 1), (128, 64, 512): (1, 1, 1),
+                (256, 64, 64): (1, 1, 1), (64, 512, 64): (1, 1, 1), (1024, 64, 32): (0, 1, 1),
+                (64, 64, 1024): (1, 1, 1), (8, 64, 2048): (1, 1, 0), (16, 1024, 64): (1, 1, 0),
+                (32, 20, 64): (1, 0, 0), (256, 256, 256): (1, 1, 1)}
+
+
+@pytest.mark.parametrize("shape", sorted(FIXED_SHAPES))
+def test_fixed_kernels_forward_and_roundtrip(gpu, shape):
+    info = gpu.plan_describe(shape)
+    assert (info["fx_rows"], info["fx_ax1"], info["fx_ax0"]) == FIXED_SHAPES[shape]
+    x = np.random.default_rng(9).standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = gpu.rfft3(x)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
+    back = gpu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 2e-5
+
+
+def test_fixed_and_generic_kernels_agree(gpu, orc, monkeypatch):
+    # the same shape through the run-time-radix kernels (MVN_NO_FIXED=1) and the specialised ones
+    shape = (64, 64, 128)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 7, 9))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    ref = orc.cpu_deconvolve(psi0, h, 8)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MVN_NO_FIXED", flag)
+        gpu.check(gpu.l.mvn_plan_store_clear())
+        assert gpu.plan_describe(shape)["fx_rows"] == (1 if flag == "0" else 0)
+        outs.append(gpu.gpu_deconvolve(psi0, h))
+    monkeypatch.delenv("MVN_NO_FIXED")
+    gpu.check(gpu.l.mvn_plan_store_clear())
+    for o in outs:
+        mx, rms = rel_err(o, ref)
+        assert mx <= MAX_REL and rms <= RMS_REL
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_fused_pipeline_invariants(gpu, orc):
+    # 8-pass pipeline with the fused last-axis passes: N iterations == N x 1 iteration bit for bit
+    shape = (64, 64, 128)
+    assert gpu.plan_describe(shape)["fx_rows"] == 1
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (5, 5, 5))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    three = gpu.gpu_deconvolve(psi0, h)
+    h.with_iterations(1)
+    one = psi0
+    for _ in range(3):
+        one = gpu.gpu_deconvolve(one, h)
+    assert np.array_equal(one, three)
+    h.with_iterations(3)
+    mx, rms = rel_err(three, orc.cpu_deconvolve(psi0, h, 8))
+    assert mx <= MAX_REL and rms <= RMS_REL
+
+
 def test_forward_matches_oracle_fft(gpu, orc):
     x = np.random.default_rng(3).standard_normal((24, 20, 36)).astype(np.float32)
     a, b = gpu.rfft3(x), orc.rfft3_forward(x, 4)

@@ -56,3 +56,17 @@ def test_final_values_random_vs_numpy():
         got = orc.final_values(psi, integral, w, 1e-4, lam)
         ref = update(psi.astype(np.float64), integral.astype(np.float64), w.astype(np.float64), lam, 1e-4)
         assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6
+
+
+def test_double_reciprocal_equals_correctly_rounded_float_division():
+    # the product computes float(1.0/double(x)) as the IEEE single-precision quotient 1.0f/x
+    # (53 >= 2*24+2 bits: no double-rounding error); pinned here against the oracle's double path
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    ones = np.ones_like(x)
+    with np.errstate(all="ignore"):
+        want = np.float32(1.0) / x
+    got = orc.compute_quotient(ones, x)
+    assert np.array_equal(got, want, equal_nan=True)

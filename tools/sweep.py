@@ -15,7 +15,7 @@ configs = [dict(), dict(MVN_T_FUSED="16"), dict(MVN_T_AXIS="8"), dict(MVN_T_ROWS
 if len(sys.argv) > 1:
     configs = [dict(kv.split("=") for kv in a.split(",") if kv) for a in sys.argv[1:]]
 for cfg in configs:
-    for kk in ("MVN_T_ROWS", "MVN_T_AXIS", "MVN_T_FUSED", "MVN_THREADS"):
+    for kk in ("MVN_T_ROWS", "MVN_T_AXIS", "MVN_T_FUSED", "MVN_THREADS", "MVN_NO_FIXED"):
         os.environ.pop(kk, None)
     os.environ.update(cfg)
     lib.check(lib.l.mvn_plan_store_clear())

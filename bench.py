@@ -51,8 +51,9 @@ def kernel_bytes(kind, d0, d1, d2):
         "rows_r2c": vol + B,            # read real volume, write half-spectrum (+ Nyquist plane)
         "rows_c2r": B + 2.5 * vol,      # read spectrum, write volume; + view (divide) or psi+weights (update): mean 1.5
         # c2r + pointwise + r2c in one pass: read spectrum, write spectrum, + view (divide) or
-        # psi + weights in, psi out (update): mean 2 volumes
-        "rows_fused": 2 * B + 2.0 * vol,
+        # psi + weights in, psi out (update)
+        "rows_fused_div": 2 * B + vol,
+        "rows_fused_upd": 2 * B + 3 * vol,
         "axis1_fwd": 2 * vol,
         "axis1_inv": 2 * vol,
         "axis0_fused": 3 * vol,         # read data, read PSF spectrum, write data
@@ -114,6 +115,9 @@ def main():
     ap.add_argument("--psf", type=int, default=31)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel events in the timed region")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=-1,
+                    help="rehearsal on a one-GPU box: put every rank on this device (needs --backend gloo)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip ms_per_fft and the small parity case (keeps rocprof --stats averages clean)")
     args = ap.parse_args()
@@ -132,8 +136,13 @@ def main():
         # torch first: the product library then binds to the HIP runtime torch already loaded
         import torch
         import torch.distributed as dist
+        if args.all_ranks_on_device >= 0:
+            local_rank = args.all_ranks_on_device
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import numpy as np
     from libmultiviewnative_amd import native
@@ -219,7 +228,7 @@ def main():
                                            "GBps": round(kernel_bytes(k, d0, d1, d2)[0] / (v[0] / v[1] * 1e-3) / 1e9, 1)}
                                        for k, v in prof.items() if v[1]}}
             traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(traffic_file):
+            if os.path.exists(traffic_file) and shape == (512, 512, 512):  # PMC passes were taken at 512^3
                 try:
                     roofline["traffic"] = json.load(open(traffic_file)).get(kind)
                 except Exception:
@@ -241,7 +250,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%dx%d f32, %d views/GPU, %d^3 PSFs, lambda=0.006" % (d0, d1, d2, V, args.psf),
                        "views_total": V * world,
-                       "update_mode": "sequential (reference order)" if world == 1 else "simultaneous + 1 RCCL all-reduce/iteration",
+                       "update_mode": "sequential (reference order)" if world == 1 else
+                       "simultaneous + 1 all-reduce/iteration (backend %s)" % args.backend,
                        "unit_of_value": "%d-view sweeps per second over all ranks" % V},
             "whole_step_GBps_25B_model": round(whole, 1),
             "whole_step_frac_of_8TBps": round(whole / HBM_PEAK_GBS, 4),

@@ -14,9 +14,10 @@ static const size_t kLdsSoftBudget = 80 * 1024;   // two workgroups per CU (160 
 static const size_t kLdsHardBudget = 160 * 1024;  // one workgroup may own the whole CU
 
 const char* kernel_kind_name(int k) {
-  static const char* names[KK_COUNT] = {"rows_r2c",  "rows_c2r",    "rows_fused", "axis1_fwd",
-                                        "axis1_inv", "axis0_fused", "axis0_fwd",  "axis0_inv",
-                                        "nyquist",   "other"};
+  static const char* names[KK_COUNT] = {"rows_r2c",    "rows_c2r",  "rows_fused_div",
+                                        "rows_fused_upd", "axis1_fwd", "axis1_inv",
+                                        "axis0_fused", "axis0_fwd",  "axis0_inv",
+                                        "nyquist",     "other"};
   return (k >= 0 && k < KK_COUNT) ? names[k] : "?";
 }
 
@@ -282,7 +283,7 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, 
   p.out_cplx = data;
   p.out_nyq = nyq;
   p.epi = epi;
-  ProfScope ps(prof, KK_ROWS_FUSED, s);
+  ProfScope ps(prof, epi.mode == MVN_EPI_UPDATE ? KK_ROWS_FUSED_UPD : KK_ROWS_FUSED, s);
   be::launch_rows_c2r_r2c(p, (long)L.rows / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
 }
 
@@ -341,8 +342,8 @@ void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler
 }
 
 void Plan3D::axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec,
-                   const cfloat* spec_nyq, be::stream_t s, Profiler* prof,
-                   be::stream_t s_nyq) const {
+                   const cfloat* spec_nyq, be::stream_t s, Profiler* prof, be::stream_t s_nyq,
+                   const cfloat* src, const cfloat* src_nyq) const {
   if (!s_nyq) s_nyq = s;
   const int kind = mode == MVN_ST_FWD ? KK_AXIS0_FWD
                                       : (mode == MVN_ST_INV ? KK_AXIS0_INV : KK_AXIS0_FUSED);
@@ -353,12 +354,14 @@ void Plan3D::axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec,
     const PassGeom& g = fx_ax0 ? gx_ax0 : (mode == MVN_ST_FWD_MUL_INV ? g_ax0f : g_ax0);
     StridedParams p = make_strided(ax0, g, data, spec, 0, cols, 1, (int)cols);
     p.fixed = fx_ax0 ? 1 : 0;
+    p.src = src;
     ProfScope ps(prof, kind, s);
     be::launch_strided(mode, p, p.tiles_per_outer, g.threads, g.lds_bytes, s);
   }
   if (L.even) {
     StridedParams p = make_strided(ax0, g_nyq0, nyq, spec_nyq, 0, L.d1, 1, L.d1);
     p.is_nyq = 1;
+    p.src = src_nyq;
     ProfScope ps(s_nyq == s ? prof : nullptr, KK_NYQ, s_nyq);
     be::launch_strided(mode, p, p.tiles_per_outer, g_nyq0.threads, g_nyq0.lds_bytes, s_nyq);
   }
@@ -515,6 +518,8 @@ Engine::~Engine() {
   be::dfree(psi_);
   be::dfree(work_);
   be::dfree(work_nyq_);
+  be::dfree(psi_spec_);
+  be::dfree(psi_spec_nyq_);
   if (!delta_external_) be::dfree(delta_);
   try {
     if (side_.s) be::stream_sync(side_.s);
@@ -677,12 +682,55 @@ void Engine::bind_delta(float* external) {
   delta_external_ = external != nullptr;
 }
 
+// Simultaneous (Jacobi) step.  psi is not touched while the local views are swept, so its
+// forward last-axis and dim1 passes are done ONCE and every view's first convolution starts at
+// the (out-of-place) dim0 pass: 7 full passes per view instead of 9.
 void Engine::compute_delta(double lambda, float min_value) {
   be::set_device(device_);
   delta_ptr();
-  work_has_psi_spectrum_ = false;
-  for (int v = 0; v < (int)views_.size(); ++v)
-    conv_pair(v, lambda, min_value, MVN_EPI_DELTA, v == 0 ? 0 : 1, false);
+  const Plan3D& P = *plan_;
+  Profiler* prof = prof_.enabled ? &prof_ : nullptr;
+  cfloat* W = (cfloat*)work_;
+  if (!psi_spec_) {
+    psi_spec_ = (float*)be::dmalloc(P.main_bytes());
+    if (P.nyq_bytes()) psi_spec_nyq_ = (cfloat*)be::dmalloc(P.nyq_bytes());
+  }
+  static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;
+  const bool fuse = P.can_fuse_rows() && !no_fuse;
+  P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);
+  P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);
+  for (int v = 0; v < (int)views_.size(); ++v) {
+    const ViewSlot& s = views_[(size_t)v];
+    if (!s.set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
+    EpilogueParams e1;
+    std::memset(&e1, 0, sizeof(e1));
+    e1.mode = MVN_EPI_DIVIDE;
+    e1.scale = 1.f;
+    e1.view = s.image;
+    EpilogueParams e2;
+    std::memset(&e2, 0, sizeof(e2));
+    e2.mode = MVN_EPI_DELTA;
+    e2.scale = 1.f;
+    e2.psi = psi_;
+    e2.weights = s.weights;
+    e2.delta = delta_;
+    e2.accumulate = v == 0 ? 0 : 1;
+    e2.lambda = lambda;
+    e2.lambda_inv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
+    e2.min_value = min_value;
+    // convolution 1 from the shared spectrum of psi
+    P.axis0(MVN_ST_FWD_MUL_INV, W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, nullptr,
+            (const cfloat*)psi_spec_, psi_spec_nyq_);
+    P.axis1(MVN_ST_INV, W, work_nyq_, stream_, prof);
+    if (fuse) {
+      P.rows_c2r_r2c(W, work_nyq_, e1, stream_, prof);
+    } else {
+      P.rows_c2r(W, work_nyq_, work_, e1, stream_, prof);
+      P.rows_r2c(work_, W, work_nyq_, stream_, prof);
+    }
+    P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof, &side_);
+    P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
+  }
 }
 
 void Engine::apply_delta() {

@@ -24,7 +24,8 @@ namespace mvn {
 enum KernelKind {
   KK_ROWS_R2C = 0,
   KK_ROWS_C2R,
-  KK_ROWS_FUSED,
+  KK_ROWS_FUSED,      // c2r + divide + r2c
+  KK_ROWS_FUSED_UPD,  // c2r + psi update + r2c
   KK_AXIS1_FWD,
   KK_AXIS1_INV,
   KK_AXIS0_FUSED,
@@ -121,8 +122,10 @@ class Plan3D {
   // stream lets the 2 MB plane ride along with the full-volume passes (see SideStream)
   void axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr,
              be::stream_t s_nyq = nullptr) const;
+  // `src` / `src_nyq` (optional) make the pass out of place: read there, write to data / nyq
   void axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec, const cfloat* spec_nyq,
-             be::stream_t s, Profiler* prof = nullptr, be::stream_t s_nyq = nullptr) const;
+             be::stream_t s, Profiler* prof = nullptr, be::stream_t s_nyq = nullptr,
+             const cfloat* src = nullptr, const cfloat* src_nyq = nullptr) const;
 
   // whole transforms, un-normalised, in place on (vol, nyq)
   void forward(float* vol, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr) const;
@@ -221,6 +224,9 @@ class Engine {
   cfloat* work_nyq_ = nullptr;
   float* delta_ = nullptr;
   bool delta_external_ = false;
+  // simultaneous mode: psi after the forward last-axis and dim1 passes, shared by all local views
+  float* psi_spec_ = nullptr;
+  cfloat* psi_spec_nyq_ = nullptr;
   bool work_has_psi_spectrum_ = false;  // work_ holds the last-axis transform of the current psi
   std::vector<ViewSlot> views_;
   Profiler prof_;

@@ -236,7 +236,7 @@ MVN_HD void fx_st_load(const StridedParams& P, long base, cfloat* buf, cfloat* t
   constexpr int TP = C::TP, U = C::U;
   const long rstep = (long)C::RPT * P.estride;
   const int q = tid % C::CH, jr = tid / C::CH;
-  const cfloat* src = P.data + base + (long)jr * P.estride + 2 * q;
+  const cfloat* src = (P.src ? P.src : P.data) + base + (long)jr * P.estride + 2 * q;
 #pragma unroll
   for (int u = 0; u < U; ++u) r.v[u] = *reinterpret_cast<const qfloat*>(src + u * rstep);
   if (MODE == MVN_ST_FWD_MUL_INV) {
@@ -311,9 +311,12 @@ MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx
 // last-axis passes for even d2 = 2H, H a power of two; T rows per tile, transposed in LDS with
 // an odd pitch and one spare row per 32 rows.  Requires rows % T == 0.
 // ---------------------------------------------------------------------------------------------
+#ifndef MVN_FX_ROWS_T
+#define MVN_FX_ROWS_T 16
+#endif
 template <int H>
 struct FxRowsCfg {
-  static constexpr int T = H <= 512 ? 16 : 8;
+  static constexpr int T = H <= 512 ? MVN_FX_ROWS_T : 8;
   static constexpr int TP = T + 1;
   static constexpr int QR = H / 2;  // 16-byte chunks per row (2 complex bins = 4 reals each)
   static constexpr int NTfull = H * T / 8;

@@ -383,7 +383,8 @@ enum MvnStridedMode { MVN_ST_FWD = 0, MVN_ST_INV = 1, MVN_ST_FWD_MUL_INV = 2 };
 
 struct StridedParams {
   AxisPlan ax;
-  cfloat* data;
+  cfloat* data;        // destination (and source, unless `src` is set)
+  const cfloat* src;   // optional separate source with the same addressing (out-of-place pass)
   const cfloat* spec;  // FWD_MUL_INV: pre-scaled PSF spectrum, same addressing as data
   long ostride;        // between outer slabs
   long estride;        // between elements of a line
@@ -414,6 +415,7 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
   const long base = o * P.ostride + (long)c0 * P.cstride;
   const int total = n * T;
   const bool single = total <= U * nthreads;
+  const cfloat* in = P.src ? P.src : P.data;
   cfloat* buf = lds;
   cfloat* alt = lds + P.lds_alt;
   const cfloat* tw = lds_stage_twiddles(lds + P.lds_tw, P.ax, tid, nthreads);
@@ -426,7 +428,7 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
       w = w < total ? w : total - 1;
       int j = w / T, c = w % T;
       c = c < ncol ? c : ncol - 1;  // clamped: the load itself is unconditional
-      v[u] = P.data[base + (long)j * P.estride + (long)c * P.cstride];
+      v[u] = in[base + (long)j * P.estride + (long)c * P.cstride];
     }
     if (MODE == MVN_ST_FWD_MUL_INV && single) {
 #pragma unroll

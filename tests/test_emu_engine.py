@@ -188,8 +188,8 @@ def test_mismatched_views_leave_psi_untouched(emu, capfd):
     assert "share image_dims_" in capfd.readouterr().err
 
 
-def test_engine_simultaneous_mode(emu):
-    shape = (12, 10, 14)
+@pytest.mark.parametrize("shape", [(12, 10, 14), (64, 64, 64)])
+def test_engine_simultaneous_mode(emu, shape):
     _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (3, 3, 3))
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
     eng = emu.engine(shape, 3)

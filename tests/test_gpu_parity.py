@@ -370,8 +370,8 @@ def test_device_minus_one_autoselects(gpu, orc):
     assert np.allclose(gpu.gpu_deconvolve(psi0, h, device=-1), orc.cpu_deconvolve(psi0, h, 1), rtol=1e-5)
 
 
-def test_simultaneous_mode_vs_oracle(gpu, orc):
-    shape = (24, 20, 28)
+@pytest.mark.parametrize("shape", [(24, 20, 28), (64, 64, 128)])
+def test_simultaneous_mode_vs_oracle(gpu, orc, shape):
     _, views, k1, k2, w, psi0 = realistic_views(shape, 4, (5, 5, 5))
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
     eng = gpu.engine(shape, 4)

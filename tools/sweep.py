@@ -14,6 +14,7 @@ configs = [dict(), dict(MVN_T_FUSED="16"), dict(MVN_T_AXIS="8"), dict(MVN_T_ROWS
            dict(MVN_THREADS="256"), dict(MVN_THREADS="256", MVN_T_ROWS="8", MVN_T_AXIS="8")]
 if len(sys.argv) > 1:
     configs = [dict(kv.split("=") for kv in a.split(",") if kv) for a in sys.argv[1:]]
+lam = float(os.environ.get("SWEEP_LAMBDA", "0.006"))
 for cfg in configs:
     for kk in ("MVN_T_ROWS", "MVN_T_AXIS", "MVN_T_FUSED", "MVN_THREADS", "MVN_NO_FIXED"):
         os.environ.pop(kk, None)
@@ -22,10 +23,10 @@ for cfg in configs:
     eng = lib.engine(shape, 1)
     eng.set_view(0, view, wts, k, k)
     eng.set_psi(psi0)
-    eng.iterate(1, 0.006, 1e-4)
-    ms = eng.time_iterate(5, 0.006, 1e-4) / 5
+    eng.iterate(1, lam, 1e-4)
+    ms = eng.time_iterate(5, lam, 1e-4) / 5
     eng.profile(True)
-    eng.iterate(3, 0.006, 1e-4)
+    eng.iterate(3, lam, 1e-4)
     eng.sync()
     prof = {n: round(t / c, 4) for n, (t, c) in eng.profile_read().items() if c}
     eng.profile(False)

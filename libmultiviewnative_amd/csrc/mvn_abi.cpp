@@ -417,6 +417,10 @@ struct FftScratch {
   }
 };
 
+// On the device a spectrum is kept in POSITION order along every axis (digit-reversed, exactly as
+// the decimation-in-frequency passes leave it; the PSF spectra are stored the same way, so the
+// RL loop never permutes anything).  These two host-buffer utilities translate to / from the
+// natural FFTW/cuFFT bin order: bin (k0,k1,k2) lives at (inv0[k0], inv1[k1], inv2[k2]).
 int mvn_fft3_r2c(int device, const int dims[3], const float* real, float* spec) {
   return guarded("mvn_fft3_r2c", [&] {
     const int dev = pick_device(device);
@@ -426,10 +430,21 @@ int mvn_fft3_r2c(int device, const int dims[3], const float* real, float* spec) 
     be::h2d_2d(f.vol, (size_t)L.RP * 4, real, (size_t)L.d2 * 4, (size_t)L.d2 * 4, L.rows, f.s);
     f.plan->forward(f.vol, f.nyq, f.s);
     const int nc = L.d2 / 2 + 1;
-    // main bins -> first C complex of every FFTW row; Nyquist plane -> last bin
-    be::d2h_2d(spec, (size_t)nc * 8, f.vol, (size_t)L.C * 8, (size_t)L.C * 8, L.rows, f.s);
-    if (L.even) be::d2h_2d(spec + 2 * (size_t)L.C, (size_t)nc * 8, f.nyq, 8, 8, L.rows, f.s);
+    std::vector<cfloat> main_h(L.rows * (size_t)L.C), nyq_h(L.nyq_cplx());
+    be::d2h(main_h.data(), f.vol, main_h.size() * sizeof(cfloat), f.s);
+    if (L.even) be::d2h(nyq_h.data(), f.nyq, nyq_h.size() * sizeof(cfloat), f.s);
     be::stream_sync(f.s);
+    const std::vector<int>& i0 = f.plan->ax0.host.inv;
+    const std::vector<int>& i1 = f.plan->ax1.host.inv;
+    const std::vector<int>& i2 = f.plan->ax2.host.inv;  // length L.h; used for even d2 only
+    cfloat* out = reinterpret_cast<cfloat*>(spec);
+    for (int k0 = 0; k0 < L.d0; ++k0)
+      for (int k1 = 0; k1 < L.d1; ++k1) {
+        const size_t srow = (size_t)i0[k0] * L.d1 + (size_t)i1[k1];
+        cfloat* o = out + ((size_t)k0 * L.d1 + k1) * (size_t)nc;
+        for (int k2 = 0; k2 < L.C; ++k2) o[k2] = main_h[srow * L.C + (L.even ? i2[k2] : k2)];
+        if (L.even) o[L.C] = nyq_h[srow];
+      }
   });
 }
 
@@ -440,8 +455,20 @@ int mvn_fft3_c2r(int device, const int dims[3], const float* spec, float* real) 
     FftScratch f(dev, dims);
     const Layout& L = f.plan->L;
     const int nc = L.d2 / 2 + 1;
-    be::h2d_2d(f.vol, (size_t)L.C * 8, spec, (size_t)nc * 8, (size_t)L.C * 8, L.rows, f.s);
-    if (L.even) be::h2d_2d(f.nyq, 8, spec + 2 * (size_t)L.C, (size_t)nc * 8, 8, L.rows, f.s);
+    std::vector<cfloat> main_h(L.rows * (size_t)L.C), nyq_h(L.nyq_cplx());
+    const std::vector<int>& i0 = f.plan->ax0.host.inv;
+    const std::vector<int>& i1 = f.plan->ax1.host.inv;
+    const std::vector<int>& i2 = f.plan->ax2.host.inv;
+    const cfloat* in = reinterpret_cast<const cfloat*>(spec);
+    for (int k0 = 0; k0 < L.d0; ++k0)
+      for (int k1 = 0; k1 < L.d1; ++k1) {
+        const size_t drow = (size_t)i0[k0] * L.d1 + (size_t)i1[k1];
+        const cfloat* o = in + ((size_t)k0 * L.d1 + k1) * (size_t)nc;
+        for (int k2 = 0; k2 < L.C; ++k2) main_h[drow * L.C + (L.even ? i2[k2] : k2)] = o[k2];
+        if (L.even) nyq_h[drow] = o[L.C];
+      }
+    be::h2d(f.vol, main_h.data(), main_h.size() * sizeof(cfloat), f.s);
+    if (L.even) be::h2d(f.nyq, nyq_h.data(), nyq_h.size() * sizeof(cfloat), f.s);
     f.plan->backward(f.vol, f.nyq, 1.f, f.s);
     be::d2h_2d(real, (size_t)L.d2 * 4, f.vol, (size_t)L.RP * 4, (size_t)L.d2 * 4, L.rows, f.s);
     be::stream_sync(f.s);

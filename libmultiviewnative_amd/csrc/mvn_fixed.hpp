@@ -240,20 +240,18 @@ MVN_HD void fx_st_load(const StridedParams& P, long base, cfloat* buf, cfloat* t
 #pragma unroll
   for (int u = 0; u < U; ++u) r.v[u] = *reinterpret_cast<const qfloat*>(src + u * rstep);
   if (MODE == MVN_ST_FWD_MUL_INV) {
-    // PSF-spectrum operands for the rows this thread multiplies later: LDS row p holds natural
-    // row rev(p); fetched now, used after the forward transform
+    // PSF-spectrum operands for the rows this thread multiplies later (the spectrum is stored
+    // in the same digit-reversed row order the forward transform produces); fetched now, used
+    // after the forward transform
+    const cfloat* sp = P.spec + base + (long)jr * P.estride + 2 * q;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = jr + u * C::RPT;
-      r.g[u] = *reinterpret_cast<const qfloat*>(P.spec + base + (long)fx_rev<N>(p) * P.estride + 2 * q);
-    }
+    for (int u = 0; u < U; ++u) r.g[u] = *reinterpret_cast<const qfloat*>(sp + u * rstep);
   }
   fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = jr + u * C::RPT;
-    const int row = (MODE == MVN_ST_INV) ? fx_inv<N>(j) : j;
-    *reinterpret_cast<qfloat*>(buf + row * TP + 2 * q) = r.v[u];
+    *reinterpret_cast<qfloat*>(buf + j * TP + 2 * q) = r.v[u];
   }
 }
 
@@ -275,13 +273,12 @@ template <int N, int MODE>
 MVN_HD void fx_st_store(const StridedParams& P, long base, const cfloat* buf, int tid) {
   typedef FxStridedCfg<N> C;
   const int q = tid % C::CH, jr = tid / C::CH;
+  const long rstep = (long)C::RPT * P.estride;
+  cfloat* dst = P.data + base + (long)jr * P.estride + 2 * q;
 #pragma unroll
-  for (int u = 0; u < C::U; ++u) {
-    const int p = jr + u * C::RPT;
-    const int grow = (MODE == MVN_ST_FWD) ? fx_rev<N>(p) : p;
-    *reinterpret_cast<qfloat*>(P.data + base + (long)grow * P.estride + 2 * q) =
-        *reinterpret_cast<const qfloat*>(buf + p * C::TP + 2 * q);
-  }
+  for (int u = 0; u < C::U; ++u)
+    *reinterpret_cast<qfloat*>(dst + u * rstep) =
+        *reinterpret_cast<const qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q);
 }
 
 template <int N, int MODE, typename Ctx>
@@ -390,8 +387,9 @@ MVN_HD void fx_r2c_store(const RowsParams& P, long r0, const cfloat* buf, int ti
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
     const int rho = e / C::QR, kk = e % C::QR;
-    const cfloat a = buf[fx_row<true>(fx_inv<H>(2 * kk)) * TP + rho];
-    const cfloat b = buf[fx_row<true>(fx_inv<H>(2 * kk + 1)) * TP + rho];
+    // spectral rows are kept in position (digit-reversed) order: bin k sits at column inv(k)
+    const cfloat a = buf[fx_row<true>(2 * kk) * TP + rho];
+    const cfloat b = buf[fx_row<true>(2 * kk + 1) * TP + rho];
     reinterpret_cast<qfloat*>(P.out_cplx + (r0 + rho) * P.C)[kk] = qmake(a.x, a.y, b.x, b.y);
   }
 }
@@ -514,8 +512,8 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
     const int rho = e / C::QR, kk = e % C::QR;
-    buf[fx_row<true>(fx_inv<H>(2 * kk)) * TP + rho] = cmake(r.v[u].x, r.v[u].y);
-    buf[fx_row<true>(fx_inv<H>(2 * kk + 1)) * TP + rho] = cmake(r.v[u].z, r.v[u].w);
+    buf[fx_row<true>(2 * kk) * TP + rho] = cmake(r.v[u].x, r.v[u].y);
+    buf[fx_row<true>(2 * kk + 1) * TP + rho] = cmake(r.v[u].z, r.v[u].w);
   }
 }
 

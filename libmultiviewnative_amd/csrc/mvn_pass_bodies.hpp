@@ -223,9 +223,10 @@ MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthr
   }
   MVN_SYNC();
   for (int w = tid; w < T * h; w += nthreads) {
-    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), k = w - rho * h;
+    // spectral rows are kept in position (digit-reversed) order: bin k sits at column inv[k]
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), p = w - rho * h;
     const long row = r0 + rho;
-    if (row < P.rows) P.out_cplx[row * P.C + k] = buf[P.ax.inv[k] * TP + rho];
+    if (row < P.rows) P.out_cplx[row * P.C + p] = buf[p * TP + rho];
   }
 }
 
@@ -267,8 +268,8 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
     for (int u = 0; u < U; ++u) {
       const int w = w0 + u * nthreads;
       if (w < total) {
-        const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), k = w - rho * h;
-        buf[P.ax.inv[k] * TP + rho] = (r0 + rho <= last_row) ? v[u] : cmake(0.f, 0.f);
+        const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), p = w - rho * h;
+        buf[p * TP + rho] = (r0 + rho <= last_row) ? v[u] : cmake(0.f, 0.f);
       }
     }
   }
@@ -437,7 +438,7 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
         w = w < total ? w : total - 1;
         int p = w / T, c = w % T;
         c = c < ncol ? c : ncol - 1;
-        g[u] = P.spec[base + (long)P.ax.rev[p] * P.estride + (long)c * P.cstride];
+        g[u] = P.spec[base + (long)p * P.estride + (long)c * P.cstride];
       }
     }
 #pragma unroll
@@ -445,8 +446,7 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
       const int w = w0 + u * nthreads;
       if (w < total) {
         const int j = w / T, c = w % T;
-        const int pos = (MODE == MVN_ST_INV) ? P.ax.inv[j] : j;
-        buf[pos * TP + c] = (c < ncol) ? v[u] : cmake(0.f, 0.f);
+        buf[j * TP + c] = (c < ncol) ? v[u] : cmake(0.f, 0.f);
       }
     }
   }
@@ -473,7 +473,7 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
             w = w < total ? w : total - 1;
             int p = w / T, c = w % T;
             c = c < ncol ? c : ncol - 1;
-            g[u] = P.spec[base + (long)P.ax.rev[p] * P.estride + (long)c * P.cstride];
+            g[u] = P.spec[base + (long)p * P.estride + (long)c * P.cstride];
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -491,10 +491,7 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
   }
   for (int w = tid; w < total; w += nthreads) {
     const int p = w / T, c = w % T;
-    if (c < ncol) {
-      const int row = (MODE == MVN_ST_FWD) ? P.ax.rev[p] : p;
-      P.data[base + (long)row * P.estride + (long)c * P.cstride] = buf[p * TP + c];
-    }
+    if (c < ncol) P.data[base + (long)p * P.estride + (long)c * P.cstride] = buf[p * TP + c];
   }
 }
 

@@ -178,26 +178,28 @@ MVN_HD void fx_stage(cfloat* buf, const cfloat* tws, int tid) {
   }
 }
 
-// all stages of a transform as phases (DIF: S = 0..ns-1, DIT: ns-1..0)
-template <int N, int T, int TP, bool PAD, int NT, int SIGN, bool DIF, int S, typename Ctx>
+// stages LO..ns-1 of a transform as phases (DIF runs them upwards from LO, DIT downwards to LO)
+template <int N, int T, int TP, bool PAD, int NT, int SIGN, bool DIF, int S, int LO, typename Ctx>
 struct FxStages {
   static MVN_HD void run(cfloat* buf, const cfloat* tws, Ctx& ctx) {
     constexpr int NT_ = NT;
     (void)NT_;
     MVN_PHASE(ctx, (fx_stage<N, T, TP, PAD, NT, S, SIGN, DIF>(buf, tws, tid)));
     constexpr int next = DIF ? S + 1 : S - 1;
-    if constexpr (next >= 0 && next < fx_nstages(N))
-      FxStages<N, T, TP, PAD, NT, SIGN, DIF, next, Ctx>::run(buf, tws, ctx);
+    if constexpr (next >= LO && next < fx_nstages(N))
+      FxStages<N, T, TP, PAD, NT, SIGN, DIF, next, LO, Ctx>::run(buf, tws, ctx);
   }
 };
 
-template <int N, int T, int TP, bool PAD, int NT, int SIGN, typename Ctx>
+template <int N, int T, int TP, bool PAD, int NT, int SIGN, int LO = 0, typename Ctx>
 MVN_HD void fx_dif(cfloat* buf, const cfloat* tws, Ctx& ctx) {
-  FxStages<N, T, TP, PAD, NT, SIGN, true, 0, Ctx>::run(buf, tws, ctx);
+  if constexpr (LO < fx_nstages(N))
+    FxStages<N, T, TP, PAD, NT, SIGN, true, LO, LO, Ctx>::run(buf, tws, ctx);
 }
-template <int N, int T, int TP, bool PAD, int NT, int SIGN, typename Ctx>
+template <int N, int T, int TP, bool PAD, int NT, int SIGN, int LO = 0, typename Ctx>
 MVN_HD void fx_dit(cfloat* buf, const cfloat* tws, Ctx& ctx) {
-  FxStages<N, T, TP, PAD, NT, SIGN, false, fx_nstages(N) - 1, Ctx>::run(buf, tws, ctx);
+  if constexpr (LO < fx_nstages(N))
+    FxStages<N, T, TP, PAD, NT, SIGN, false, fx_nstages(N) - 1, LO, Ctx>::run(buf, tws, ctx);
 }
 
 template <int NT>
@@ -307,6 +309,14 @@ MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx
 // ---------------------------------------------------------------------------------------------
 // last-axis passes for even d2 = 2H, H a power of two; T rows per tile, transposed in LDS with
 // an odd pitch and one spare row per 32 rows.  Requires rows % T == 0.
+//
+// Stage 0 of the transform (radix 8, stride M0 = H/8) is done in registers right next to the
+// global accesses, with the bins of one row on neighbouring lanes ("row-fastest": slot w ->
+// j2 = w % M0, row = w / M0), so that
+//   r2c : global real row -> first forward stage -> LDS                (no separate load phase)
+//   c2r : LDS -> last inverse stage -> pointwise epilogue -> global    (no separate store phase)
+//   c2r+r2c fused: ... last inverse stage -> epilogue -> first forward stage ... all in registers
+// The remaining stages use the column-fastest mapping of fx_stage.
 // ---------------------------------------------------------------------------------------------
 #ifndef MVN_FX_ROWS_T
 #define MVN_FX_ROWS_T 16
@@ -315,43 +325,70 @@ template <int H>
 struct FxRowsCfg {
   static constexpr int T = H <= 512 ? MVN_FX_ROWS_T : 8;
   static constexpr int TP = T + 1;
-  static constexpr int QR = H / 2;  // 16-byte chunks per row (2 complex bins = 4 reals each)
+  static constexpr int QR = H / 2;  // 16-byte chunks per spectral row (2 complex bins each)
   static constexpr int NTfull = H * T / 8;
   static constexpr int NT = NTfull >= 512 ? 512 : (NTfull >= 64 ? NTfull : 64);
-  static constexpr int U = T * QR / NT;  // 16-byte loads per thread
+  static constexpr int U = T * QR / NT;  // 16-byte spectral loads/stores per thread
+  static constexpr int R0 = fx_radix(H, 0);
+  static constexpr int M0 = fx_M(H, 0);
+  static constexpr int IT0 = (M0 * T) / NT;  // stage-0 butterflies per thread
   static constexpr int ROWS = fx_rows_alloc(H, true);
   static constexpr int TILE = (ROWS * TP + 1) & ~1;  // keeps the tables behind it 16-byte aligned
   static constexpr int lds_cfloats = TILE + fx_twsize(H) + (H / 2 + 2);
   static_assert(fx_pow2(H) && H >= 32 && H <= 1024, "unsupported fixed length");
   static_assert((T * QR) % NT == 0, "tile must divide");
+  static_assert((M0 * T) % NT == 0 && IT0 >= 1 && R0 == 8, "stage 0: whole radix-8 butterflies per thread");
 };
 
 template <int H>
 struct FxRowsRegs {
   qfloat v[FxRowsCfg<H>::U];
-  qfloat ea[FxRowsCfg<H>::U];
-  qfloat eb[FxRowsCfg<H>::U];
+  // epilogue operands of the elements this thread finishes in the last inverse stage
+  cfloat ea[FxRowsCfg<H>::IT0][FxRowsCfg<H>::R0];
+  cfloat eb[FxRowsCfg<H>::IT0][FxRowsCfg<H>::R0];
 };
 
-template <int H>
-MVN_HD void fx_r2c_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, cfloat* twr,
-                        FxRowsRegs<H>& r, int tid) {
-  typedef FxRowsCfg<H> C;
-  constexpr int TP = C::TP, NT = C::NT, U = C::U;
+// twiddles of one butterfly row: R entries, 16-byte aligned
+template <int R>
+MVN_HD void fx_load_tw_row(const cfloat* row, cfloat* tw) {
+  const qfloat* t4 = reinterpret_cast<const qfloat*>(row);
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = tid + u * NT;
-    const int rho = e / C::QR, jj = e % C::QR;
-    r.v[u] = reinterpret_cast<const qfloat*>(P.in_real + (r0 + rho) * P.RP)[jj];
+  for (int k = 0; k < R / 2; ++k) {
+    const qfloat t = t4[k];
+    tw[2 * k] = cmake(t.x, t.y);
+    tw[2 * k + 1] = cmake(t.z, t.w);
+  }
+}
+
+// r2c phase A: global load -> first forward stage in registers -> LDS
+template <int H>
+MVN_HD void fx_r2c_load_stage0(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, cfloat* twr,
+                               int tid) {
+  typedef FxRowsCfg<H> C;
+  constexpr int TP = C::TP, NT = C::NT, R = C::R0, M = C::M0;
+  cfloat a[C::IT0][R];
+#pragma unroll
+  for (int it = 0; it < C::IT0; ++it) {
+    const int w = tid + it * NT;
+    const int j2 = w % M, rho = w / M;
+    const cfloat* src = reinterpret_cast<const cfloat*>(P.in_real + (r0 + rho) * P.RP) + j2;
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[it][j] = src[j * M];
   }
   fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(H), tid);
   fx_copy_table<NT>(twr, P.twr, H / 2 + 1, tid);
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = tid + u * NT;
-    const int rho = e / C::QR, jj = e % C::QR;
-    buf[fx_row<true>(2 * jj) * TP + rho] = cmake(r.v[u].x, r.v[u].y);
-    buf[fx_row<true>(2 * jj + 1) * TP + rho] = cmake(r.v[u].z, r.v[u].w);
+  for (int it = 0; it < C::IT0; ++it) {
+    const int w = tid + it * NT;
+    const int j2 = w % M, rho = w / M;
+    cfloat tw[R];
+    fx_load_tw_row<R>(P.ax.tws + j2 * R, tw);  // stage 0 opens the table; the LDS copy is not ready yet
+    dftR<R, -1>(a[it]);
+#pragma unroll
+    for (int k = 1; k < R; ++k) a[it][k] = cmul(a[it][k], tw[k]);
+    cfloat* p = buf + fx_row<true>(j2) * TP + rho;
+#pragma unroll
+    for (int k = 0; k < R; ++k) p[fx_rowoff<true, R, M>(k) * TP] = a[it][k];
   }
 }
 
@@ -403,77 +440,35 @@ MVN_HD void fx_rows_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* buf = lds;
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
-  MVN_PHASE(ctx, (fx_r2c_load<H>(P, r0, buf, tws, twr, r, tid)));
-  fx_dif<H, T, TP, true, NT, -1>(buf, tws, ctx);
+  MVN_PHASE(ctx, (fx_r2c_load_stage0<H>(P, r0, buf, tws, twr, tid)));
+  fx_dif<H, T, TP, true, NT, -1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
 
-// epilogue on four consecutive reals (one 16-byte unit); operands were fetched in phase 0
 MVN_HD float fx_blend(float w, float next, float last) {
   MVN_FP_EXACT
   return w * (next - last) + last;
 }
-MVN_HD float fx_delta(float w, float next, float last) {
-  MVN_FP_EXACT
-  return w * (next - last);
-}
 
-// Same arithmetic, but hands the four results back instead of (DIVIDE) / in addition to (UPDATE)
-// storing them: they are the input of the forward transform fused behind this pass.
-MVN_HD qfloat fx_epilogue_quad_value(const EpilogueParams& e, long i, qfloat x, qfloat a, qfloat b) {
+// pair epilogue of the fused pass: the result y = (y[2j], y[2j+1]) is the packed input z[j] of the
+// next forward transform; UPDATE also writes psi
+MVN_HD cfloat fx_epilogue_pair_value(const EpilogueParams& e, long i, cfloat z, cfloat a, cfloat b) {
   MVN_FP_EXACT
-  x = qmake(x.x * e.scale, x.y * e.scale, x.z * e.scale, x.w * e.scale);
-  if (e.mode == MVN_EPI_DIVIDE)
-    return qmake(mvn_quotient(a.x, x.x), mvn_quotient(a.y, x.y), mvn_quotient(a.z, x.z),
-                 mvn_quotient(a.w, x.w));
+  const float x0 = z.x * e.scale, x1 = z.y * e.scale;
+  if (e.mode == MVN_EPI_DIVIDE) return cmake(mvn_quotient(a.x, x0), mvn_quotient(a.y, x1));
   if (e.mode == MVN_EPI_UPDATE) {
-    const float n0 = mvn_next_value(a.x, x.x, e.lambda, e.lambda_inv, e.min_value);
-    const float n1 = mvn_next_value(a.y, x.y, e.lambda, e.lambda_inv, e.min_value);
-    const float n2 = mvn_next_value(a.z, x.z, e.lambda, e.lambda_inv, e.min_value);
-    const float n3 = mvn_next_value(a.w, x.w, e.lambda, e.lambda_inv, e.min_value);
-    const qfloat y = qmake(fx_blend(b.x, n0, a.x), fx_blend(b.y, n1, a.y), fx_blend(b.z, n2, a.z),
-                           fx_blend(b.w, n3, a.w));
-    *reinterpret_cast<qfloat*>(e.psi + i) = y;
+    const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);
+    const float n1 = mvn_next_value(a.y, x1, e.lambda, e.lambda_inv, e.min_value);
+    const cfloat y = cmake(fx_blend(b.x, n0, a.x), fx_blend(b.y, n1, a.y));
+    *reinterpret_cast<cfloat*>(e.psi + i) = y;
     return y;
   }
-  return x;  // STORE: plain inverse followed by a forward transform
+  return cmake(x0, x1);
 }
 
-MVN_HD void fx_epilogue_quad(const EpilogueParams& e, float* out, long i, qfloat x, qfloat a,
-                             qfloat b) {
-  MVN_FP_EXACT
-  x = qmake(x.x * e.scale, x.y * e.scale, x.z * e.scale, x.w * e.scale);
-  switch (e.mode) {
-    case MVN_EPI_STORE: *reinterpret_cast<qfloat*>(out + i) = x; break;
-    case MVN_EPI_DIVIDE:
-      *reinterpret_cast<qfloat*>(out + i) = qmake(mvn_quotient(a.x, x.x), mvn_quotient(a.y, x.y),
-                                                  mvn_quotient(a.z, x.z), mvn_quotient(a.w, x.w));
-      break;
-    case MVN_EPI_UPDATE: {
-      const float n0 = mvn_next_value(a.x, x.x, e.lambda, e.lambda_inv, e.min_value);
-      const float n1 = mvn_next_value(a.y, x.y, e.lambda, e.lambda_inv, e.min_value);
-      const float n2 = mvn_next_value(a.z, x.z, e.lambda, e.lambda_inv, e.min_value);
-      const float n3 = mvn_next_value(a.w, x.w, e.lambda, e.lambda_inv, e.min_value);
-      *reinterpret_cast<qfloat*>(e.psi + i) = qmake(fx_blend(b.x, n0, a.x), fx_blend(b.y, n1, a.y),
-                                                    fx_blend(b.z, n2, a.z), fx_blend(b.w, n3, a.w));
-    } break;
-    case MVN_EPI_DELTA: {
-      const float n0 = mvn_next_value(a.x, x.x, e.lambda, e.lambda_inv, e.min_value);
-      const float n1 = mvn_next_value(a.y, x.y, e.lambda, e.lambda_inv, e.min_value);
-      const float n2 = mvn_next_value(a.z, x.z, e.lambda, e.lambda_inv, e.min_value);
-      const float n3 = mvn_next_value(a.w, x.w, e.lambda, e.lambda_inv, e.min_value);
-      qfloat d = qmake(fx_delta(b.x, n0, a.x), fx_delta(b.y, n1, a.y), fx_delta(b.z, n2, a.z),
-                       fx_delta(b.w, n3, a.w));
-      if (e.accumulate) {
-        const qfloat old = *reinterpret_cast<const qfloat*>(e.delta + i);
-        d = qmake(old.x + d.x, old.y + d.y, old.z + d.z, old.w + d.w);
-      }
-      *reinterpret_cast<qfloat*>(e.delta + i) = d;
-    } break;
-  }
-}
-
+// c2r phase 0: spectral rows -> LDS (position order both sides), plus the epilogue operands of the
+// elements this thread will finish in the last inverse stage, fetched a whole transform ahead
 template <int H>
 MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, cfloat* twr,
                         FxRowsRegs<H>& r, int tid) {
@@ -485,8 +480,6 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
     const int rho = e / C::QR, kk = e % C::QR;
     r.v[u] = reinterpret_cast<const qfloat*>(P.in_cplx + (r0 + rho) * P.C)[kk];
   }
-  // epilogue operands, fetched a whole transform ahead of their use; the (uniform) mode branch
-  // stays outside the unrolled loops so that each branch is straight-line code
   // Two independent guarded loops, each filling ONE array: if both arrays were written in
   // sibling branches LLVM sinks the stores into a common block with a selected address and the
   // register arrays fall back to scratch.
@@ -494,16 +487,21 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
   const float* pa = mode == MVN_EPI_DIVIDE ? P.epi.view : P.epi.psi;
   if (mode != MVN_EPI_STORE) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = tid + u * NT;
-      r.ea[u] = *reinterpret_cast<const qfloat*>(pa + (r0 + e / C::QR) * P.RP + 4 * (e % C::QR));
+    for (int it = 0; it < C::IT0; ++it) {
+      const int w = tid + it * NT;
+      const cfloat* src = reinterpret_cast<const cfloat*>(pa + (r0 + w / C::M0) * P.RP) + (w % C::M0);
+#pragma unroll
+      for (int jo = 0; jo < C::R0; ++jo) r.ea[it][jo] = src[jo * C::M0];
     }
   }
   if (mode == MVN_EPI_UPDATE || mode == MVN_EPI_DELTA) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = tid + u * NT;
-      r.eb[u] = *reinterpret_cast<const qfloat*>(P.epi.weights + (r0 + e / C::QR) * P.RP + 4 * (e % C::QR));
+    for (int it = 0; it < C::IT0; ++it) {
+      const int w = tid + it * NT;
+      const cfloat* src =
+          reinterpret_cast<const cfloat*>(P.epi.weights + (r0 + w / C::M0) * P.RP) + (w % C::M0);
+#pragma unroll
+      for (int jo = 0; jo < C::R0; ++jo) r.eb[it][jo] = src[jo * C::M0];
     }
   }
   fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(H), tid);
@@ -542,39 +540,42 @@ MVN_HD void fx_c2r_pre(const RowsParams& P, long r0, cfloat* buf, const cfloat* 
   }
 }
 
-template <int H>
-MVN_HD void fx_c2r_epi(const RowsParams& P, long r0, const cfloat* buf, FxRowsRegs<H>& r, int tid) {
+// c2r last phase: LDS -> last inverse stage in registers -> pointwise epilogue -> either the
+// real rows in global memory (KEEP = false) or, for the fused pass, straight into the first
+// forward stage of the next transform and back to LDS (KEEP = true)
+template <int H, bool KEEP>
+MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, const cfloat* tws,
+                                   FxRowsRegs<H>& r, int tid) {
   typedef FxRowsCfg<H> C;
-  constexpr int TP = C::TP, NT = C::NT, U = C::U;
+  constexpr int TP = C::TP, NT = C::NT, R = C::R0, M = C::M0;
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = tid + u * NT;
-    const int rho = e / C::QR, jj = e % C::QR;
-    const cfloat z0 = buf[fx_row<true>(2 * jj) * TP + rho];
-    const cfloat z1 = buf[fx_row<true>(2 * jj + 1) * TP + rho];
-    fx_epilogue_quad(P.epi, P.out_real, (r0 + rho) * P.RP + 4 * jj, qmake(z0.x, z0.y, z1.x, z1.y),
-                     r.ea[u], r.eb[u]);
-  }
-}
-
-// fused form: the epilogue results stay in LDS as the packed input z[j] = y[2j] + i y[2j+1] of
-// the NEXT convolution's forward last-axis transform
-template <int H>
-MVN_HD void fx_c2r_epi_keep(const RowsParams& P, long r0, cfloat* buf, FxRowsRegs<H>& r, int tid) {
-  typedef FxRowsCfg<H> C;
-  constexpr int TP = C::TP, NT = C::NT, U = C::U;
+  for (int it = 0; it < C::IT0; ++it) {
+    const int w = tid + it * NT;
+    const int j2 = w % M, rho = w / M;
+    cfloat* p = buf + fx_row<true>(j2) * TP + rho;
+    cfloat a[R];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = tid + u * NT;
-    const int rho = e / C::QR, jj = e % C::QR;
-    cfloat* p0 = buf + fx_row<true>(2 * jj) * TP + rho;
-    cfloat* p1 = buf + fx_row<true>(2 * jj + 1) * TP + rho;
-    const cfloat z0 = *p0;
-    const cfloat z1 = *p1;
-    const qfloat y = fx_epilogue_quad_value(P.epi, (r0 + rho) * P.RP + 4 * jj,
-                                            qmake(z0.x, z0.y, z1.x, z1.y), r.ea[u], r.eb[u]);
-    *p0 = cmake(y.x, y.y);
-    *p1 = cmake(y.z, y.w);
+    for (int k = 0; k < R; ++k) a[k] = p[fx_rowoff<true, R, M>(k) * TP];
+    cfloat tw[R];
+    fx_load_tw_row<R>(tws + j2 * R, tw);
+#pragma unroll
+    for (int k = 1; k < R; ++k) a[k] = cmul(a[k], cconj(tw[k]));
+    dftR<R, +1>(a);  // a[jo] = z[j2 + M*jo] = (x[2j], x[2j+1])
+    const long i0 = (r0 + rho) * P.RP + 2 * j2;
+    if (KEEP) {
+#pragma unroll
+      for (int jo = 0; jo < R; ++jo)
+        a[jo] = fx_epilogue_pair_value(P.epi, i0 + 2 * jo * M, a[jo], r.ea[it][jo], r.eb[it][jo]);
+      dftR<R, -1>(a);
+#pragma unroll
+      for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[k]);
+#pragma unroll
+      for (int k = 0; k < R; ++k) p[fx_rowoff<true, R, M>(k) * TP] = a[k];
+    } else {
+#pragma unroll
+      for (int jo = 0; jo < R; ++jo)
+        mvn_epilogue_pair(P.epi, P.out_real, i0 + 2 * jo * M, a[jo], r.ea[it][jo], r.eb[it][jo]);
+    }
   }
 }
 
@@ -593,9 +594,9 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_c2r_load<H>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
-  fx_dit<H, T, TP, true, NT, +1>(buf, tws, ctx);
-  MVN_PHASE(ctx, (fx_c2r_epi_keep<H>(P, r0, buf, r, tid)));
-  fx_dif<H, T, TP, true, NT, -1>(buf, tws, ctx);
+  fx_dit<H, T, TP, true, NT, +1, 1>(buf, tws, ctx);
+  MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, true>(P, r0, buf, tws, r, tid)));
+  fx_dif<H, T, TP, true, NT, -1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
@@ -611,6 +612,6 @@ MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_c2r_load<H>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
-  fx_dit<H, T, TP, true, NT, +1>(buf, tws, ctx);
-  MVN_PHASE(ctx, (fx_c2r_epi<H>(P, r0, buf, r, tid)));
+  fx_dit<H, T, TP, true, NT, +1, 1>(buf, tws, ctx);
+  MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, false>(P, r0, buf, tws, r, tid)));
 }

@@ -75,8 +75,11 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams
   fx_rows_c2r_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
+#ifndef MVN_ROWS_FUSED_WAVES
+#define MVN_ROWS_FUSED_WAVES 1
+#endif
 template <int H>
-__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p) {
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT, MVN_ROWS_FUSED_WAVES) kx_rows_c2r_r2c(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;

@@ -13,7 +13,10 @@
  *    the in/out buffer is left untouched;
  *  - convolution is cyclic on exactly the given dims with the kernel centre on the origin --
  *    the semantics of the reference's CPU path (inc/cpu_convolve.h, no_padd), which is the
- *    parity target; callers pre-pad for linear behaviour as they already do for the CPU path;
+ *    parity target; callers pre-pad for linear behaviour as they already do for the CPU path.
+ *    The environment variable MVN_PAD_MODE=zero switches inplace_gpu_deconvolve to the reference
+ *    GPU entry's zero_padd policy instead (embed in image + kernel - 1, crop on exit;
+ *    src/multiviewnative.cu:26-27,128, inc/padd_utils.h:121-138);
  *  - the CPU entry points (inplace_cpu_deconvolve / inplace_cpu_convolution,
  *    inc/multiviewnative.h:43-51) are NOT exported by the product library: this library has
  *    no CPU fallback.  Their restatement lives in oracle/ as test infrastructure.

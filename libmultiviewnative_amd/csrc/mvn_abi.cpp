@@ -2,6 +2,7 @@
 // engine ABI (include/mvn_engine_api.h).  Nothing escapes as an exception; failures leave the
 // caller's in/out buffers untouched, print one diagnostic to stderr and never terminate the
 // host process (SURVEY.md 8b "Errors").
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -143,10 +144,31 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
       if (d.weights_dims_ && to_shape(d.weights_dims_) != dims)
         throw std::invalid_argument("weights_dims_ must equal image_dims_ (view " + std::to_string(v) + ")");
     }
+    // Padding policy.  Default = the CPU path's no_padd (cyclic on exactly image_dims_, the parity
+    // target).  MVN_PAD_MODE=zero selects the reference GPU entry's zero_padd
+    // (src/multiviewnative.cu:26-27,128; inc/padd_utils.h:121-138;
+    // src/gpu_deconvolve_methods.cuh:366-449,537-549): every stack is embedded at offset
+    // (kernel-1)/2 in a zero volume of extent image + kernel - 1 (maxima over views and both
+    // kernels), the loop runs cyclically on that volume and psi is cropped back on exit.
+    const char* pm = std::getenv("MVN_PAD_MODE");
+    const bool zero_pad = pm && std::strcmp(pm, "zero") == 0;
+    shape_t ext = dims;
+    int off[3] = {0, 0, 0};
+    if (zero_pad) {
+      for (int d = 0; d < 3; ++d) {
+        int kmax = 1;
+        for (int v = 0; v < V; ++v) {
+          kmax = std::max(kmax, input.data_[v].kernel1_dims_[d]);
+          kmax = std::max(kmax, input.data_[v].kernel2_dims_[d]);
+        }
+        ext[d] = dims[d] + kmax - 1;
+        off[d] = (kmax - 1) / 2;
+      }
+    }
     // memory heuristic of src/multiviewnative.cu:94-119, restated for the resident layout:
     // 4 volumes per view (view, weights, two spectra) + psi + work (+ slack)
     be::set_device(dev);
-    Layout L(dims[0], dims[1], dims[2]);
+    Layout L(ext[0], ext[1], ext[2]);
     const double need = (4.0 * V + 2.0) * (double)L.B() * 1.02;
     size_t free_b = 0, total_b = 0;
     be::device_mem_info(&free_b, &total_b);
@@ -155,15 +177,44 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
                   need / 1048576.0, free_b / 1048576.0, need < free_b ? "all on device!" : "does not fit");
     if (need >= (double)free_b)
       throw std::runtime_error("FFT: Unable to run on GPU due to memory constraints");
-    Engine eng(dev, dims, V);
+    Engine eng(dev, ext, V);
+    if (!zero_pad) {
+      for (int v = 0; v < V; ++v) {
+        const view_data& d = input.data_[v];
+        eng.set_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+      }
+      eng.set_psi(psi);
+      eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
+      eng.sync();
+      eng.get_psi(psi);
+      return;
+    }
+    // zero_padd: embed on the host (insert_at_offsets, inc/padd_utils.h:160-190), crop on exit
+    const size_t en = (size_t)ext[0] * ext[1] * ext[2];
+    auto embed = [&](const float* src, std::vector<float>& dst) {
+      std::fill(dst.begin(), dst.end(), 0.f);
+      for (int z = 0; z < dims[0]; ++z)
+        for (int y = 0; y < dims[1]; ++y)
+          std::memcpy(&dst[((size_t)(z + off[0]) * ext[1] + (y + off[1])) * ext[2] + off[2]],
+                      src + ((size_t)z * dims[1] + y) * dims[2], sizeof(float) * (size_t)dims[2]);
+    };
+    std::vector<float> a(en), b(en);
     for (int v = 0; v < V; ++v) {
       const view_data& d = input.data_[v];
-      eng.set_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+      embed(d.image_, a);
+      embed(d.weights_, b);
+      eng.set_view(v, a.data(), b.data(), d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
     }
-    eng.set_psi(psi);
+    embed(psi, a);
+    eng.set_psi(a.data());
     eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
     eng.sync();
-    eng.get_psi(psi);
+    eng.get_psi(a.data());
+    for (int z = 0; z < dims[0]; ++z)
+      for (int y = 0; y < dims[1]; ++y)
+        std::memcpy(psi + ((size_t)z * dims[1] + y) * dims[2],
+                    &a[((size_t)(z + off[0]) * ext[1] + (y + off[1])) * ext[2] + off[2]],
+                    sizeof(float) * (size_t)dims[2]);
   });
 }
 

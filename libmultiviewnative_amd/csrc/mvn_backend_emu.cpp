@@ -102,7 +102,14 @@ static void emu_rows_fused(const RowsParams& p, long ntiles) {
     std::vector<char> lds(sizeof(cfloat) * FxRowsCfg<H>::lds_cfloats + 64);
     std::unique_ptr<Ctx> ctx(new Ctx());
 #pragma omp for schedule(static)
-    for (long t = 0; t < ntiles; ++t) fx_rows_c2r_r2c_body<H>(p, t, (cfloat*)lds.data(), *ctx);
+    for (long t = 0; t < ntiles; ++t) {
+      cfloat* l = (cfloat*)lds.data();
+      switch (p.epi.mode) {
+        case MVN_EPI_DIVIDE: fx_rows_c2r_r2c_body<H, MVN_EPI_DIVIDE>(p, t, l, *ctx); break;
+        case MVN_EPI_UPDATE: fx_rows_c2r_r2c_body<H, MVN_EPI_UPDATE>(p, t, l, *ctx); break;
+        default: fx_rows_c2r_r2c_body<H, MVN_EPI_STORE>(p, t, l, *ctx); break;
+      }
+    }
   }
 }
 
@@ -126,8 +133,15 @@ static void emu_rows_fixed(const RowsParams& p, long ntiles, bool r2c) {
     for (long t = 0; t < ntiles; ++t) {
       if (r2c)
         fx_rows_r2c_body<H>(p, t, (cfloat*)lds.data(), *ctx);
-      else
-        fx_rows_c2r_body<H>(p, t, (cfloat*)lds.data(), *ctx);
+      else {
+        cfloat* l = (cfloat*)lds.data();
+        switch (p.epi.mode) {
+          case MVN_EPI_DIVIDE: fx_rows_c2r_body<H, MVN_EPI_DIVIDE>(p, t, l, *ctx); break;
+          case MVN_EPI_UPDATE: fx_rows_c2r_body<H, MVN_EPI_UPDATE>(p, t, l, *ctx); break;
+          case MVN_EPI_DELTA: fx_rows_c2r_body<H, MVN_EPI_DELTA>(p, t, l, *ctx); break;
+          default: fx_rows_c2r_body<H, MVN_EPI_STORE>(p, t, l, *ctx); break;
+        }
+      }
     }
   }
 }

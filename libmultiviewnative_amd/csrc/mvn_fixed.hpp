@@ -452,12 +452,14 @@ MVN_HD float fx_blend(float w, float next, float last) {
 }
 
 // pair epilogue of the fused pass: the result y = (y[2j], y[2j+1]) is the packed input z[j] of the
-// next forward transform; UPDATE also writes psi
+// next forward transform; UPDATE also writes psi.  EPI is the compile-time MvnEpilogue mode: the
+// kernels are instantiated per mode so that a mode's dead operand registers and branches vanish.
+template <int EPI>
 MVN_HD cfloat fx_epilogue_pair_value(const EpilogueParams& e, long i, cfloat z, cfloat a, cfloat b) {
   MVN_FP_EXACT
   const float x0 = z.x * e.scale, x1 = z.y * e.scale;
-  if (e.mode == MVN_EPI_DIVIDE) return cmake(mvn_quotient(a.x, x0), mvn_quotient(a.y, x1));
-  if (e.mode == MVN_EPI_UPDATE) {
+  if (EPI == MVN_EPI_DIVIDE) return cmake(mvn_quotient(a.x, x0), mvn_quotient(a.y, x1));
+  if (EPI == MVN_EPI_UPDATE) {
     const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);
     const float n1 = mvn_next_value(a.y, x1, e.lambda, e.lambda_inv, e.min_value);
     const cfloat y = cmake(fx_blend(b.x, n0, a.x), fx_blend(b.y, n1, a.y));
@@ -469,7 +471,7 @@ MVN_HD cfloat fx_epilogue_pair_value(const EpilogueParams& e, long i, cfloat z, 
 
 // c2r phase 0: spectral rows -> LDS (position order both sides), plus the epilogue operands of the
 // elements this thread will finish in the last inverse stage, fetched a whole transform ahead
-template <int H>
+template <int H, int EPI>
 MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, cfloat* twr,
                         FxRowsRegs<H>& r, int tid) {
   typedef FxRowsCfg<H> C;
@@ -480,10 +482,7 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
     const int rho = e / C::QR, kk = e % C::QR;
     r.v[u] = reinterpret_cast<const qfloat*>(P.in_cplx + (r0 + rho) * P.C)[kk];
   }
-  // Two independent guarded loops, each filling ONE array: if both arrays were written in
-  // sibling branches LLVM sinks the stores into a common block with a selected address and the
-  // register arrays fall back to scratch.
-  const int mode = P.epi.mode;
+  constexpr int mode = EPI;
   const float* pa = mode == MVN_EPI_DIVIDE ? P.epi.view : P.epi.psi;
   if (mode != MVN_EPI_STORE) {
 #pragma unroll
@@ -543,7 +542,7 @@ MVN_HD void fx_c2r_pre(const RowsParams& P, long r0, cfloat* buf, const cfloat* 
 // c2r last phase: LDS -> last inverse stage in registers -> pointwise epilogue -> either the
 // real rows in global memory (KEEP = false) or, for the fused pass, straight into the first
 // forward stage of the next transform and back to LDS (KEEP = true)
-template <int H, bool KEEP>
+template <int H, bool KEEP, int EPI>
 MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, const cfloat* tws,
                                    FxRowsRegs<H>& r, int tid) {
   typedef FxRowsCfg<H> C;
@@ -565,7 +564,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
     if (KEEP) {
 #pragma unroll
       for (int jo = 0; jo < R; ++jo)
-        a[jo] = fx_epilogue_pair_value(P.epi, i0 + 2 * jo * M, a[jo], r.ea[it][jo], r.eb[it][jo]);
+        a[jo] = fx_epilogue_pair_value<EPI>(P.epi, i0 + 2 * jo * M, a[jo], r.ea[it][jo], r.eb[it][jo]);
       dftR<R, -1>(a);
 #pragma unroll
       for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[k]);
@@ -574,7 +573,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
     } else {
 #pragma unroll
       for (int jo = 0; jo < R; ++jo)
-        mvn_epilogue_pair(P.epi, P.out_real, i0 + 2 * jo * M, a[jo], r.ea[it][jo], r.eb[it][jo]);
+        mvn_epilogue_pair_t<EPI>(P.epi, P.out_real, i0 + 2 * jo * M, a[jo], r.ea[it][jo], r.eb[it][jo]);
     }
   }
 }
@@ -583,7 +582,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
 // of the pointwise step), writes the half-spectrum of the result in place (UPDATE also writes
 // psi).  The reference runs cufftExecC2R, a pointwise kernel and cufftExecR2C here
 // (inc/gpu_convolve.cuh:140-141 + inc/cuda_kernels.cuh:14-112 + inc/gpu_convolve.cuh:121).
-template <int H, typename Ctx>
+template <int H, int EPI, typename Ctx>
 MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& ctx) {
   typedef FxRowsCfg<H> C;
   constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
@@ -592,16 +591,16 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
   cfloat* buf = lds;
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
-  MVN_PHASE(ctx, (fx_c2r_load<H>(P, r0, buf, tws, twr, r, tid)));
+  MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
   fx_dit<H, T, TP, true, NT, +1, 1>(buf, tws, ctx);
-  MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, true>(P, r0, buf, tws, r, tid)));
+  MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, true, EPI>(P, r0, buf, tws, r, tid)));
   fx_dif<H, T, TP, true, NT, -1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
 
-template <int H, typename Ctx>
+template <int H, int EPI, typename Ctx>
 MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& ctx) {
   typedef FxRowsCfg<H> C;
   constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
@@ -610,8 +609,8 @@ MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* buf = lds;
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
-  MVN_PHASE(ctx, (fx_c2r_load<H>(P, r0, buf, tws, twr, r, tid)));
+  MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
   fx_dit<H, T, TP, true, NT, +1, 1>(buf, tws, ctx);
-  MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, false>(P, r0, buf, tws, r, tid)));
+  MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, false, EPI>(P, r0, buf, tws, r, tid)));
 }

@@ -67,23 +67,20 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_r2c(const RowsParams
   fx_rows_r2c_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
-template <int H>
+template <int H, int EPI>
 __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_c2r_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_c2r_body<H, EPI>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
-#ifndef MVN_ROWS_FUSED_WAVES
-#define MVN_ROWS_FUSED_WAVES 1
-#endif
-template <int H>
-__global__ void __launch_bounds__(FxRowsCfg<H>::NT, MVN_ROWS_FUSED_WAVES) kx_rows_c2r_r2c(const RowsParams p) {
+template <int H, int EPI>
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_c2r_r2c_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_c2r_r2c_body<H, EPI>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
 template <int N, int MODE>
@@ -318,7 +315,15 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
     check_aligned16(p.in_cplx, "input");
     check_aligned16(p.out_real, "output");
     switch (p.h) {
-#define X(H) case H: launch_pass(kx_rows_c2r<H>, p, nblocks, nthreads, lds_bytes, s); return;
+#define X(H)                                                                                  \
+  case H:                                                                                     \
+    switch (p.epi.mode) {                                                                     \
+      case MVN_EPI_DIVIDE: launch_pass(kx_rows_c2r<H, MVN_EPI_DIVIDE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      case MVN_EPI_UPDATE: launch_pass(kx_rows_c2r<H, MVN_EPI_UPDATE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      case MVN_EPI_DELTA: launch_pass(kx_rows_c2r<H, MVN_EPI_DELTA>, p, nblocks, nthreads, lds_bytes, s); break;   \
+      default: launch_pass(kx_rows_c2r<H, MVN_EPI_STORE>, p, nblocks, nthreads, lds_bytes, s); break;             \
+    }                                                                                         \
+    return;
       MVN_FIXED_ROWS_LENGTHS(X)
 #undef X
       default: throw std::invalid_argument("mvn: no fixed rows kernel for this length");
@@ -338,7 +343,14 @@ void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t
   check_aligned16(p.in_cplx, "input");
   check_aligned16(p.out_cplx, "output");
   switch (p.h) {
-#define X(H) case H: launch_pass(kx_rows_c2r_r2c<H>, p, nblocks, nthreads, lds_bytes, s); return;
+#define X(H)                                                                                  \
+  case H:                                                                                     \
+    switch (p.epi.mode) {                                                                     \
+      case MVN_EPI_DIVIDE: launch_pass(kx_rows_c2r_r2c<H, MVN_EPI_DIVIDE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      case MVN_EPI_UPDATE: launch_pass(kx_rows_c2r_r2c<H, MVN_EPI_UPDATE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      default: launch_pass(kx_rows_c2r_r2c<H, MVN_EPI_STORE>, p, nblocks, nthreads, lds_bytes, s); break;             \
+    }                                                                                         \
+    return;
     MVN_FIXED_ROWS_LENGTHS(X)
 #undef X
     default: throw std::invalid_argument("mvn: no fixed rows kernel for this length");

@@ -141,6 +141,15 @@ MVN_HD void mvn_epilogue_pair(const EpilogueParams& e, float* out, long i, cfloa
   }
 }
 
+// the same with the mode as a template constant (fixed-length kernels)
+template <int EPI>
+MVN_HD void mvn_epilogue_pair_t(const EpilogueParams& e, float* out, long i, cfloat z, cfloat a,
+                                cfloat b) {
+  EpilogueParams ee = e;
+  ee.mode = EPI;
+  mvn_epilogue_pair(ee, out, i, z, a, b);
+}
+
 #define MVN_ROWS_U 8
 
 // ---------------------------------------------------------------------------------------------

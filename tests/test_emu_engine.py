@@ -221,3 +221,35 @@ def test_pointwise_entry_points(emu):
     for lam in (0.0, 0.006):
         assert np.array_equal(emu.compute_final_values(psi, integral, w, 1e-4, lam),
                               orc.final_values(psi, integral, w, 1e-4, lam))
+
+
+def _zero_padd_reference(orc, psi0, views, k1, k2, w, lam, minv, its):
+    """The reference GPU entry's zero_padd policy applied by hand (inc/padd_utils.h:121-138,
+    src/gpu_deconvolve_methods.cuh:366-449,537-549), run through the CPU oracle."""
+    dims = psi0.shape
+    kmax = [max(max(a.shape[d], b.shape[d]) for a, b in zip(k1, k2)) for d in range(3)]
+    ext = tuple(dims[d] + kmax[d] - 1 for d in range(3))
+    off = tuple((kmax[d] - 1) // 2 for d in range(3))
+    sl = tuple(slice(off[d], off[d] + dims[d]) for d in range(3))
+
+    def embed(x):
+        out = np.zeros(ext, np.float32)
+        out[sl] = x
+        return out
+
+    h = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], lam, minv, its)
+    return orc.cpu_deconvolve(embed(psi0), h, 4)[sl]
+
+
+def test_zero_padd_mode_matches_reference_gpu_policy(emu, monkeypatch):
+    shape = (20, 16, 24)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 3, 7))
+    k2[1] = k2[1][:3]  # kernels of different extents: the policy takes the maxima
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    cyclic = emu.gpu_deconvolve(psi0, h)
+    monkeypatch.setenv("MVN_PAD_MODE", "zero")
+    padded = emu.gpu_deconvolve(psi0, h)
+    monkeypatch.delenv("MVN_PAD_MODE")
+    ref = _zero_padd_reference(orc, psi0, views, k1, k2, w, 0.006, 1e-4, 3)
+    assert np.abs(padded - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert np.abs(padded - cyclic).max() > 1e-3 * np.abs(ref).max()  # the two policies do differ

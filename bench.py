@@ -188,6 +188,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:
+        # communicator set-up (lazy in RCCL) must never land in the timed region, even with --warmup 0
+        dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        delta.zero_()
     run(args.warmup)
     if not args.no_profile:
         eng.profile(True)

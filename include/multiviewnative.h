@@ -16,7 +16,9 @@
  *    parity target; callers pre-pad for linear behaviour as they already do for the CPU path.
  *    The environment variable MVN_PAD_MODE=zero switches inplace_gpu_deconvolve to the reference
  *    GPU entry's zero_padd policy instead (embed in image + kernel - 1, crop on exit;
- *    src/multiviewnative.cu:26-27,128, inc/padd_utils.h:121-138);
+ *    src/multiviewnative.cu:26-27,128, inc/padd_utils.h:121-138).  With MVN_PAD_GOOD_SIZE=1 on top
+ *    the padded extents grow to the next 2^a 3^b 5^c 7^d and the quotient is 0 wherever a view
+ *    voxel is exactly 0 (the reference's 0 * 1/0 would be NaN in the added zeros);
  *  - the CPU entry points (inplace_cpu_deconvolve / inplace_cpu_convolution,
  *    inc/multiviewnative.h:43-51) are NOT exported by the product library: this library has
  *    no CPU fallback.  Their restatement lives in oracle/ as test infrastructure.

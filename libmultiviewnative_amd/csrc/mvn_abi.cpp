@@ -165,6 +165,24 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
         off[d] = (kmax - 1) / 2;
       }
     }
+    // MVN_PAD_GOOD_SIZE=1 (zero mode only): grow every padded extent to the next 2^a 3^b 5^c 7^d
+    // so that no axis needs the O(r^2) prime stage (542 = 2*271 -> 560).  The extra zeros lie
+    // beyond the PSF's reach, where the blurred estimate is exactly or nearly 0; the quotient is
+    // therefore guarded (view == 0 -> 0) in this mode, the one deliberate deviation from the
+    // reference's pointwise math (which yields 0 * 1/0 = NaN there).
+    const char* gs = std::getenv("MVN_PAD_GOOD_SIZE");
+    const bool good_size = zero_pad && gs && *gs && std::strcmp(gs, "0") != 0;
+    if (good_size)
+      for (int d = 0; d < 3; ++d) {
+        int n = ext[d];
+        for (;; ++n) {
+          int m = n;
+          for (int p : {2, 3, 5, 7})
+            while (m % p == 0) m /= p;
+          if (m == 1) break;
+        }
+        ext[d] = n;
+      }
     // memory heuristic of src/multiviewnative.cu:94-119, restated for the resident layout:
     // 4 volumes per view (view, weights, two spectra) + psi + work (+ slack)
     be::set_device(dev);
@@ -178,6 +196,7 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
     if (need >= (double)free_b)
       throw std::runtime_error("FFT: Unable to run on GPU due to memory constraints");
     Engine eng(dev, ext, V);
+    eng.set_quotient_guard(good_size);
     if (!zero_pad) {
       for (int v = 0; v < V; ++v) {
         const view_data& d = input.data_[v];

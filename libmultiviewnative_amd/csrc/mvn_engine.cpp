@@ -123,7 +123,8 @@ PassGeom Plan3D::pick_geom(int n, bool generic, bool rows, int max_t) {
   PassGeom g;
   bool found = false;
   for (int pass = 0; pass < 2 && !found; ++pass) {
-    const size_t budget = pass == 0 ? kLdsSoftBudget : kLdsHardBudget;
+    size_t budget = pass == 0 ? kLdsSoftBudget : kLdsHardBudget;
+    if (pass == 0 && env_int("MVN_LDS_SOFT_KB", 0) > 0) budget = (size_t)env_int("MVN_LDS_SOFT_KB", 0) * 1024;
     for (int i = 0; i < 5; ++i) {
       const int T = cand[i];
       if (T > max_t) continue;
@@ -617,6 +618,7 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   e1.mode = MVN_EPI_DIVIDE;
   e1.scale = 1.f;  // 1/N already lives in the PSF spectrum
   e1.view = s.image;
+  e1.guard_zero_view = quotient_guard_ ? 1 : 0;
 
   EpilogueParams e2;
   std::memset(&e2, 0, sizeof(e2));
@@ -707,6 +709,7 @@ void Engine::compute_delta(double lambda, float min_value) {
     e1.mode = MVN_EPI_DIVIDE;
     e1.scale = 1.f;
     e1.view = s.image;
+    e1.guard_zero_view = quotient_guard_ ? 1 : 0;
     EpilogueParams e2;
     std::memset(&e2, 0, sizeof(e2));
     e2.mode = MVN_EPI_DELTA;

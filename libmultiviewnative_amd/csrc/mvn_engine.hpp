@@ -209,6 +209,8 @@ class Engine {
   void bind_delta(float* external);
   float* psi_ptr() { return psi_; }
   size_t volume_floats() const { return plan_->L.real_floats(); }
+  // quotient 0 wherever the view is exactly 0 (see EpilogueParams::guard_zero_view)
+  void set_quotient_guard(bool on) { quotient_guard_ = on; }
   void sync();
 
  private:
@@ -227,7 +229,8 @@ class Engine {
   // simultaneous mode: psi after the forward last-axis and dim1 passes, shared by all local views
   float* psi_spec_ = nullptr;
   cfloat* psi_spec_nyq_ = nullptr;
-  bool work_has_psi_spectrum_ = false;  // work_ holds the last-axis transform of the current psi
+  bool work_has_psi_spectrum_ = false;
+  bool quotient_guard_ = false;  // work_ holds the last-axis transform of the current psi
   std::vector<ViewSlot> views_;
   Profiler prof_;
 };

@@ -458,7 +458,8 @@ template <int EPI>
 MVN_HD cfloat fx_epilogue_pair_value(const EpilogueParams& e, long i, cfloat z, cfloat a, cfloat b) {
   MVN_FP_EXACT
   const float x0 = z.x * e.scale, x1 = z.y * e.scale;
-  if (EPI == MVN_EPI_DIVIDE) return cmake(mvn_quotient(a.x, x0), mvn_quotient(a.y, x1));
+  if (EPI == MVN_EPI_DIVIDE)
+    return cmake(mvn_quotient_g(a.x, x0, e.guard_zero_view), mvn_quotient_g(a.y, x1, e.guard_zero_view));
   if (EPI == MVN_EPI_UPDATE) {
     const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);
     const float n1 = mvn_next_value(a.y, x1, e.lambda, e.lambda_inv, e.min_value);

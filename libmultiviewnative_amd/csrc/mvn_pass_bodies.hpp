@@ -45,7 +45,13 @@ struct EpilogueParams {
   double lambda;        // > 0 selects the Tikhonov branch
   float lambda_inv;     // float(1.f / lambda)   (inc/cpu_kernels.h:71)
   float min_value;
+  int guard_zero_view;  // DIVIDE: a view voxel that is exactly 0 gives quotient 0 even where the
+                        // blurred estimate is 0 (0 * 1/0 = NaN otherwise); only set for the
+                        // good-size zero-padding mode, whose extra zeros lie beyond the PSF's reach
 };
+
+// quotient with the optional guard above
+MVN_HD float mvn_quotient_g(float view, float blurred, int guard);
 
 // inc/cpu_kernels.h:22-25: TransferT temp = 1. / out; out = in * temp, i.e. a DOUBLE divide
 // rounded to float.  Double carries 53 >= 2*24+2 bits, so that double rounding is innocuous and
@@ -57,6 +63,10 @@ MVN_HD float mvn_quotient(float view, float blurred) {
   MVN_FP_EXACT
   float t = 1.0f / blurred;
   return view * t;
+}
+
+MVN_HD float mvn_quotient_g(float view, float blurred, int guard) {
+  return (guard && view == 0.f) ? 0.f : mvn_quotient(view, blurred);
 }
 
 // clamp / regularise chain of inc/cpu_kernels.h:40-49 (lambda == 0) and :75-86 (lambda > 0)
@@ -82,7 +92,7 @@ MVN_HD void mvn_epilogue(const EpilogueParams& e, float* out, long i, float x) {
   x *= e.scale;
   switch (e.mode) {
     case MVN_EPI_STORE: out[i] = x; break;
-    case MVN_EPI_DIVIDE: out[i] = mvn_quotient(e.view[i], x); break;
+    case MVN_EPI_DIVIDE: out[i] = mvn_quotient_g(e.view[i], x, e.guard_zero_view); break;
     case MVN_EPI_UPDATE: {
       float last = e.psi[i];
       float next = mvn_next_value(last, x, e.lambda, e.lambda_inv, e.min_value);
@@ -121,7 +131,8 @@ MVN_HD void mvn_epilogue_pair(const EpilogueParams& e, float* out, long i, cfloa
   switch (e.mode) {
     case MVN_EPI_STORE: *reinterpret_cast<cfloat*>(out + i) = cmake(x0, x1); break;
     case MVN_EPI_DIVIDE:
-      *reinterpret_cast<cfloat*>(out + i) = cmake(mvn_quotient(a.x, x0), mvn_quotient(a.y, x1));
+      *reinterpret_cast<cfloat*>(out + i) = cmake(mvn_quotient_g(a.x, x0, e.guard_zero_view),
+                                                  mvn_quotient_g(a.y, x1, e.guard_zero_view));
       break;
     case MVN_EPI_UPDATE: {
       const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);

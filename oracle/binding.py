@@ -47,6 +47,8 @@ def _setup(l):
     l.oracle_deconvolve_simultaneous.argtypes = [c_float_p, Workspace, C.c_int]
     l.oracle_deconvolve_simultaneous_step.argtypes = [c_float_p, Workspace, C.c_int, C.c_int,
                                                       c_float_p, C.c_int]
+    l.oracle_set_quotient_guard.argtypes = [C.c_int]
+    l.oracle_set_quotient_guard.restype = None
     l.oracle_last_timing.argtypes = [C.POINTER(C.c_double)]
     l.oracle_last_timing.restype = None
     l.oracle_threads.argtypes = [C.c_int]
@@ -137,6 +139,10 @@ def cpu_deconvolve(psi, holder, nthreads=1):
     out = np.ascontiguousarray(psi, dtype=np.float32).copy()
     lib().inplace_cpu_deconvolve(_fp(out), holder.ws, nthreads)
     return out
+
+
+def set_quotient_guard(on):
+    lib().oracle_set_quotient_guard(1 if on else 0)
 
 
 def last_timing():

@@ -393,9 +393,18 @@ static void half_inplace(float* image, const int* dims, const float* fwd_kernel,
  * Pointwise kernels (serial forms are canonical: inc/cpu_kernels.h:19-90)
  * ---------------------------------------------------------------------------------------- */
 
+/* Not in the reference: mirrors the product's MVN_PAD_GOOD_SIZE mode, where a view voxel that is
+ * exactly 0 gives quotient 0 (instead of 0 * 1/0 = NaN) -- see include/multiviewnative.h. */
+static int g_quotient_guard = 0;
+void oracle_set_quotient_guard(int on) { g_quotient_guard = on; }
+
 /* inc/cpu_kernels.h:19-26 */
 void oracle_compute_quotient(const float* input, float* output, size_t size) {
   for (size_t i = 0; i < size; ++i) {
+    if (g_quotient_guard && input[i] == 0.f) {
+      output[i] = 0.f;
+      continue;
+    }
     float temp = (float)(1. / (double)output[i]);
     output[i] = input[i] * temp;
   }

@@ -253,3 +253,41 @@ def test_zero_padd_mode_matches_reference_gpu_policy(emu, monkeypatch):
     ref = _zero_padd_reference(orc, psi0, views, k1, k2, w, 0.006, 1e-4, 3)
     assert np.abs(padded - ref).max() <= 1e-4 * np.abs(ref).max()
     assert np.abs(padded - cyclic).max() > 1e-3 * np.abs(ref).max()  # the two policies do differ
+
+
+def test_zero_padd_good_size_mode(emu, monkeypatch):
+    # MVN_PAD_GOOD_SIZE=1: padded extents grow to 2^a 3^b 5^c 7^d (here 19+5-1=23 -> 24,
+    # 13+3-1=15, 17+7-1=23 -> 24) and the quotient is guarded where the view is exactly 0.
+    # Delta PSFs make the blurred estimate EXACTLY 0 in the border: without the guard -> NaN.
+    shape = (19, 13, 17)
+    views, k1, k2, w = synthetic_views(shape, 2, 5, 7)
+    k1 = [k[:, 1:4, :] for k in k1]
+    k2 = [k[1:6, 2:5, :] for k in k2]
+    k1 = [np.ascontiguousarray(k) for k in k1]
+    k2 = [np.ascontiguousarray(k) for k in k2]
+    psi0 = np.full(shape, 3.0, np.float32)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
+    monkeypatch.setenv("MVN_PAD_MODE", "zero")
+    monkeypatch.setenv("MVN_PAD_GOOD_SIZE", "1")
+    got = emu.gpu_deconvolve(psi0, h)
+    monkeypatch.delenv("MVN_PAD_MODE")
+    monkeypatch.delenv("MVN_PAD_GOOD_SIZE")
+    assert np.isfinite(got).all()
+    # oracle on hand-padded stacks of the same good size, same guard
+    ext, off = (24, 15, 24), (2, 1, 3)
+    sl = tuple(slice(o, o + s) for o, s in zip(off, shape))
+
+    def embed(x):
+        out = np.zeros(ext, np.float32)
+        out[sl] = x
+        return out
+
+    hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-3, 2)
+    orc.set_quotient_guard(True)
+    try:
+        ref = orc.cpu_deconvolve(embed(psi0), hp, 2)[sl]
+    finally:
+        orc.set_quotient_guard(False)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    # the closed form of the synthetic data holds in the interior (constant views, delta PSFs)
+    assert abs(float(got[9, 6, 8]) - 30.0 * (np.sqrt(1 + 2 * 0.006 * 30.0) - 1) / (0.006 * 30.0)) < 1e-2

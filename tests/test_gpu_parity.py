@@ -340,6 +340,26 @@ def test_full_size_512_closed_form(gpu):
     assert np.abs(psi - 37.72946).max() < 2e-4 * 37.72946
 
 
+def test_full_size_config5_closed_form(gpu):
+    # BASELINE.json configs[4] shape (320 x 1920 x 1920, dims[2] fastest; mixed radix 2^a*3*5 on
+    # every axis) through the same size-independent property, 2 of its 6 views to bound host memory
+    shape = (320, 1920, 1920)
+    eng = gpu.engine(shape, 2)
+    _, k1, k2, _ = synthetic_views((1, 1, 1), 2, 31, 31)
+    ones = np.ones(shape, np.float32)
+    buf = np.empty(shape, np.float32)
+    for v in range(2):
+        buf.fill(16.0 + 4.0 * v)
+        eng.set_view(v, buf, ones, k1[v], k2[v])
+    buf.fill(3.0)
+    eng.set_psi(buf)
+    eng.iterate(2, 0.006, 1e-3)
+    psi = eng.get_psi()
+    eng.close()
+    want = (np.sqrt(1 + 2 * 0.006 * (20.0 * 3 / 2)) - 1) / 0.006  # f((16+4v)(v+2)/(v+1)), v = 1
+    assert np.abs(psi - want).max() < 2e-4 * want
+
+
 def test_loop_invariants(gpu, orc):
     shape = (16, 16, 16)
     views, k1, k2, w = synthetic_views(shape, 3, 3, 5)
@@ -456,3 +476,41 @@ def test_zero_padd_mode_matches_reference_gpu_policy(gpu, orc, monkeypatch):
     ref = _zero_padd_reference(orc, psi0, views, k1, k2, w, 0.006, 1e-4, 3)
     assert np.abs(padded - ref).max() <= 1e-4 * np.abs(ref).max()
     assert np.abs(padded - cyclic).max() > 1e-3 * np.abs(ref).max()  # the two policies do differ
+
+
+def test_zero_padd_good_size_mode(gpu, orc, monkeypatch):
+    # MVN_PAD_GOOD_SIZE=1: padded extents grow to 2^a 3^b 5^c 7^d (here 19+5-1=23 -> 24,
+    # 13+3-1=15, 17+7-1=23 -> 24) and the quotient is guarded where the view is exactly 0.
+    # Delta PSFs make the blurred estimate EXACTLY 0 in the border: without the guard -> NaN.
+    shape = (19, 13, 17)
+    views, k1, k2, w = synthetic_views(shape, 2, 5, 7)
+    k1 = [k[:, 1:4, :] for k in k1]
+    k2 = [k[1:6, 2:5, :] for k in k2]
+    k1 = [np.ascontiguousarray(k) for k in k1]
+    k2 = [np.ascontiguousarray(k) for k in k2]
+    psi0 = np.full(shape, 3.0, np.float32)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
+    monkeypatch.setenv("MVN_PAD_MODE", "zero")
+    monkeypatch.setenv("MVN_PAD_GOOD_SIZE", "1")
+    got = gpu.gpu_deconvolve(psi0, h)
+    monkeypatch.delenv("MVN_PAD_MODE")
+    monkeypatch.delenv("MVN_PAD_GOOD_SIZE")
+    assert np.isfinite(got).all()
+    # oracle on hand-padded stacks of the same good size, same guard
+    ext, off = (24, 15, 24), (2, 1, 3)
+    sl = tuple(slice(o, o + s) for o, s in zip(off, shape))
+
+    def embed(x):
+        out = np.zeros(ext, np.float32)
+        out[sl] = x
+        return out
+
+    hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-3, 2)
+    orc.set_quotient_guard(True)
+    try:
+        ref = orc.cpu_deconvolve(embed(psi0), hp, 2)[sl]
+    finally:
+        orc.set_quotient_guard(False)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    # the closed form of the synthetic data holds in the interior (constant views, delta PSFs)
+    assert abs(float(got[9, 6, 8]) - 30.0 * (np.sqrt(1 + 2 * 0.006 * 30.0) - 1) / (0.006 * 30.0)) < 1e-2

@@ -334,7 +334,11 @@ struct FxRowsCfg {
   static constexpr int IT0 = (M0 * T) / NT;  // stage-0 butterflies per thread
   static constexpr int ROWS = fx_rows_alloc(H, true);
   static constexpr int TILE = (ROWS * TP + 1) & ~1;  // keeps the tables behind it 16-byte aligned
-  static constexpr int lds_cfloats = TILE + fx_twsize(H) + (H / 2 + 2);
+  // tile | stage twiddles | d2-th roots (H/2+1, padded to even) | pair table (H/2 entries of 2 ints)
+  static constexpr int TWR = (H / 2 + 2) & ~1;
+  static constexpr int lds_cfloats = TILE + fx_twsize(H) + TWR + H / 2;
+  static constexpr int ITP = (H / 2 * T) / NT;  // bin pairs per thread in the real<->complex step
+  static_assert((H / 2 * T) % NT == 0, "pair step must divide");
   static_assert(fx_pow2(H) && H >= 32 && H <= 1024, "unsupported fixed length");
   static_assert((T * QR) % NT == 0, "tile must divide");
   static_assert((M0 * T) % NT == 0 && IT0 >= 1 && R0 == 8, "stage 0: whole radix-8 butterflies per thread");
@@ -347,6 +351,24 @@ struct FxRowsRegs {
   cfloat ea[FxRowsCfg<H>::IT0][FxRowsCfg<H>::R0];
   cfloat eb[FxRowsCfg<H>::IT0][FxRowsCfg<H>::R0];
 };
+
+// LDS offsets (in cfloat, row * TP) of the two bins the real<->complex step combines: entry k
+// (0 < k < H/2) = {bin k, bin H-k}; entry 0 = {bin 0, bin H/2} (the two self-paired bins).
+// Built in LDS once per workgroup so that the per-pair index math is one 8-byte LDS read.
+struct FxPair {
+  int a, b;
+};
+
+template <int H>
+MVN_HD void fx_build_pair_table(FxPair* tab, int tid) {
+  typedef FxRowsCfg<H> C;
+  for (int k = tid; k < H / 2; k += C::NT) {
+    FxPair e;
+    e.a = fx_row<true>(fx_inv<H>(k)) * C::TP;
+    e.b = fx_row<true>(fx_inv<H>(k == 0 ? H / 2 : H - k)) * C::TP;
+    tab[k] = e;
+  }
+}
 
 // twiddles of one butterfly row: R entries, 16-byte aligned
 template <int R>
@@ -377,6 +399,7 @@ MVN_HD void fx_r2c_load_stage0(const RowsParams& P, long r0, cfloat* buf, cfloat
   }
   fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(H), tid);
   fx_copy_table<NT>(twr, P.twr, H / 2 + 1, tid);
+  fx_build_pair_table<H>(reinterpret_cast<FxPair*>(twr + C::TWR), tid);
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * NT;
@@ -392,26 +415,32 @@ MVN_HD void fx_r2c_load_stage0(const RowsParams& P, long r0, cfloat* buf, cfloat
   }
 }
 
+// real -> half-complex step on the packed transform Z (positions via the pair table):
+// X[k] = E - i w^k D, X[H-k] = conj(E) - i conj(w^k D), E = (Z[k] + conj Z[H-k])/2, D = (Z[k] - conj Z[H-k])/2
 template <int H>
 MVN_HD void fx_r2c_post(const RowsParams& P, long r0, cfloat* buf, const cfloat* twr, int tid) {
   typedef FxRowsCfg<H> C;
-  constexpr int T = C::T, TP = C::TP, NT = C::NT;
-  constexpr int npairs = H / 2 + 1;
-  for (int w = tid; w < npairs * T; w += NT) {
-    const int k = w / T, rho = w % T;
-    const int m = (H - k) & (H - 1);
-    const int pk = fx_row<true>(fx_inv<H>(k)), pm = fx_row<true>(fx_inv<H>(m));
-    const cfloat zk = buf[pk * TP + rho];
+  constexpr int T = C::T, NT = C::NT;
+  const FxPair* tab = reinterpret_cast<const FxPair*>(twr + C::TWR);
+#pragma unroll
+  for (int it = 0; it < C::ITP; ++it) {
+    const int i = tid + it * NT;
+    const int k = i / T, rho = i % T;
+    const FxPair t = tab[k];
+    cfloat* pa = buf + t.a + rho;
+    cfloat* pb = buf + t.b + rho;
+    const cfloat zk = *pa;
+    const cfloat zm = *pb;
     if (k == 0) {
-      buf[pk * TP + rho] = cmake(zk.x + zk.y, 0.f);
-      P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);
+      *pa = cmake(zk.x + zk.y, 0.f);                       // DC
+      P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);       // Nyquist, kept in its own plane
+      *pb = cconj(zm);                                     // bin H/2 pairs with itself
     } else {
-      const cfloat zm = buf[pm * TP + rho];
       const cfloat E = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
       const cfloat D = cmake(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
       const cfloat G = cmul(twr[k], D);
-      buf[pk * TP + rho] = cadd(E, cmul_si<-1>(G));
-      if (m != k) buf[pm * TP + rho] = cadd(cconj(E), cmul_si<-1>(cconj(G)));
+      *pa = cadd(E, cmul_si<-1>(G));
+      *pb = cadd(cconj(E), cmul_si<-1>(cconj(G)));
     }
   }
 }
@@ -506,6 +535,7 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
   }
   fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(H), tid);
   fx_copy_table<NT>(twr, P.twr, H / 2 + 1, tid);
+  fx_build_pair_table<H>(reinterpret_cast<FxPair*>(twr + C::TWR), tid);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
@@ -515,27 +545,33 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
   }
 }
 
+// half-complex -> real step: Z[k] = E + i O, Z[H-k] = conj(E) + i conj(O),
+// E = X[k] + conj X[H-k], O = (X[k] - conj X[H-k]) exp(+2 pi i k / d2)
 template <int H>
 MVN_HD void fx_c2r_pre(const RowsParams& P, long r0, cfloat* buf, const cfloat* twr, int tid) {
   typedef FxRowsCfg<H> C;
-  constexpr int T = C::T, TP = C::TP, NT = C::NT;
-  constexpr int npairs = H / 2 + 1;
-  for (int w = tid; w < npairs * T; w += NT) {
-    const int k = w / T, rho = w % T;
-    const int m = (H - k) & (H - 1);
-    const int pk = fx_row<true>(fx_inv<H>(k)), pm = fx_row<true>(fx_inv<H>(m));
-    const cfloat xk = buf[pk * TP + rho];
+  constexpr int T = C::T, NT = C::NT;
+  const FxPair* tab = reinterpret_cast<const FxPair*>(twr + C::TWR);
+#pragma unroll
+  for (int it = 0; it < C::ITP; ++it) {
+    const int i = tid + it * NT;
+    const int k = i / T, rho = i % T;
+    const FxPair t = tab[k];
+    cfloat* pa = buf + t.a + rho;
+    cfloat* pb = buf + t.b + rho;
+    const cfloat xk = *pa;
+    const cfloat xm = *pb;
     if (k == 0) {
       // imaginary parts of the DC and Nyquist bins are ignored, as FFTW's c2r does
       const float xh = P.in_nyq[r0 + rho].x;
-      buf[pk * TP + rho] = cmake(xk.x + xh, xk.x - xh);
+      *pa = cmake(xk.x + xh, xk.x - xh);
+      *pb = cmake(2.f * xm.x, -2.f * xm.y);  // bin H/2 pairs with itself: Z = 2 conj(X)
     } else {
-      const cfloat xm = buf[pm * TP + rho];
       const cfloat E = cmake(xk.x + xm.x, xk.y - xm.y);
       const cfloat Dk = cmake(xk.x - xm.x, xk.y + xm.y);
       const cfloat O = cmul(Dk, cconj(twr[k]));
-      buf[pk * TP + rho] = cadd(E, cmul_si<+1>(O));
-      if (m != k) buf[pm * TP + rho] = cadd(cconj(E), cmul_si<+1>(cconj(O)));
+      *pa = cadd(E, cmul_si<+1>(O));
+      *pb = cadd(cconj(E), cmul_si<+1>(cconj(O)));
     }
   }
 }

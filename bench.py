@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1,
                     help="rehearsal on a one-GPU box: put every rank on this device (needs --backend gloo)")
+    ap.add_argument("--simultaneous", action="store_true",
+                    help="run the simultaneous-update (Jacobi) loop even on one rank (what every rank of an N>1 run computes)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip ms_per_fft and the small parity case (keeps rocprof --stats averages clean)")
     args = ap.parse_args()
@@ -173,6 +175,8 @@ def main():
         eng.bind_delta(delta.data_ptr())
         driver = SimultaneousDriver(eng, delta, dist,
                                     after_collective=lambda: torch.cuda.current_stream().synchronize())
+    elif args.simultaneous:
+        driver = SimultaneousDriver(eng, None, None)
 
     def run(steps):
         if driver is None:
@@ -254,7 +258,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%dx%d f32, %d views/GPU, %d^3 PSFs, lambda=0.006" % (d0, d1, d2, V, args.psf),
                        "views_total": V * world,
-                       "update_mode": "sequential (reference order)" if world == 1 else
+                       "update_mode": "sequential (reference order)" if driver is None else "simultaneous, single rank" if world == 1 else
                        "simultaneous + 1 all-reduce/iteration (backend %s)" % args.backend,
                        "unit_of_value": "%d-view sweeps per second over all ranks" % V},
             "whole_step_GBps_25B_model": round(whole, 1),

@@ -322,6 +322,16 @@ void SideStream::destroy() {
   fork = join = nullptr;
 }
 
+void SideStream::fork_from(be::stream_t main) {
+  be::event_record(fork, main);
+  be::stream_wait_event(s, fork);
+}
+
+void SideStream::join_into(be::stream_t main) {
+  be::event_record(join, s);
+  be::stream_wait_event(main, join);
+}
+
 void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof,
                    be::stream_t s_nyq) const {
   if (!s_nyq) s_nyq = s;
@@ -390,19 +400,13 @@ void Plan3D::middle_passes(cfloat* work, cfloat* work_nyq, const cfloat* spec,
                            SideStream* side) const {
   be::stream_t sn = s;
   if (side && side->s && L.even) {
-    // fork: the plane was written by the last-axis pass just enqueued on s
-    be::event_record(side->fork, s);
-    be::stream_wait_event(side->s, side->fork);
+    side->fork_from(s);  // the plane was written by the last-axis pass just enqueued on s
     sn = side->s;
   }
   axis1(MVN_ST_FWD, work, work_nyq, s, prof, sn);
   axis0(MVN_ST_FWD_MUL_INV, work, work_nyq, spec, spec_nyq, s, prof, sn);
   axis1(MVN_ST_INV, work, work_nyq, s, prof, sn);
-  if (sn != s) {
-    // join: the next last-axis pass on s reads the plane
-    be::event_record(side->join, sn);
-    be::stream_wait_event(s, side->join);
-  }
+  if (sn != s) side->join_into(s);  // the next last-axis pass on s reads the plane
 }
 
 void Plan3D::convolve(const float* in_real, cfloat* work, cfloat* work_nyq, const cfloat* spec,
@@ -699,8 +703,12 @@ void Engine::compute_delta(double lambda, float min_value) {
   }
   static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;
   const bool fuse = P.can_fuse_rows() && !no_fuse;
+  static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;
+  const bool use_side = !no_side && side_.s && P.L.even;
+  be::stream_t sn = use_side ? side_.s : stream_;
   P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);
-  P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);
+  if (use_side) side_.fork_from(stream_);
+  P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof, sn);
   for (int v = 0; v < (int)views_.size(); ++v) {
     const ViewSlot& s = views_[(size_t)v];
     if (!s.set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
@@ -721,17 +729,21 @@ void Engine::compute_delta(double lambda, float min_value) {
     e2.lambda = lambda;
     e2.lambda_inv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
     e2.min_value = min_value;
-    // convolution 1 from the shared spectrum of psi
-    P.axis0(MVN_ST_FWD_MUL_INV, W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, nullptr,
+    // convolution 1 from the shared spectrum of psi; the Nyquist-plane launches ride on the side
+    // stream (forked again per view: the previous view's last pass still reads work_nyq_)
+    if (use_side && v > 0) side_.fork_from(stream_);
+    P.axis0(MVN_ST_FWD_MUL_INV, W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
             (const cfloat*)psi_spec_, psi_spec_nyq_);
-    P.axis1(MVN_ST_INV, W, work_nyq_, stream_, prof);
+    P.axis1(MVN_ST_INV, W, work_nyq_, stream_, prof, sn);
+    if (use_side) side_.join_into(stream_);
     if (fuse) {
       P.rows_c2r_r2c(W, work_nyq_, e1, stream_, prof);
     } else {
       P.rows_c2r(W, work_nyq_, work_, e1, stream_, prof);
       P.rows_r2c(work_, W, work_nyq_, stream_, prof);
     }
-    P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof, &side_);
+    P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof,
+                    use_side ? &side_ : nullptr);
     P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
   }
 }

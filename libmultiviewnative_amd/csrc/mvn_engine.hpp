@@ -88,6 +88,9 @@ struct SideStream {
   be::event_t fork = nullptr, join = nullptr;
   void create();
   void destroy();
+  // side stream waits for everything enqueued on `main` so far / `main` waits for the side stream
+  void fork_from(be::stream_t main);
+  void join_into(be::stream_t main);
 };
 
 class Plan3D {

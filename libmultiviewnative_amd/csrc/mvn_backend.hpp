@@ -58,8 +58,9 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int nthreads, 
                      stream_t s);
 void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int nthreads, size_t lds_bytes,
                      stream_t s);
-// fixed-length only: c2r + pointwise epilogue + r2c of the result in one pass (p.fixed must be 1;
-// reads p.in_cplx / p.in_nyq, writes p.out_cplx / p.out_nyq, UPDATE also writes epi.psi)
+// even d2 only: c2r + pointwise epilogue + r2c of the result in one pass (reads p.in_cplx /
+// p.in_nyq, writes p.out_cplx / p.out_nyq, UPDATE also writes epi.psi); p.fixed selects the
+// compile-time specialised kernel
 void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int nthreads, size_t lds_bytes,
                          stream_t s);
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,

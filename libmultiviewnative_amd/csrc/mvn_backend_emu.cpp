@@ -22,6 +22,17 @@
 namespace mvn {
 namespace be {
 
+#define MVN_DISPATCH_T(T_, CALL)                                   \
+  switch (T_) {                                                    \
+    case 16: { constexpr int TT = 16; CALL; } break;               \
+    case 8: { constexpr int TT = 8; CALL; } break;                 \
+    case 4: { constexpr int TT = 4; CALL; } break;                 \
+    case 2: { constexpr int TT = 2; CALL; } break;                 \
+    case 1: { constexpr int TT = 1; CALL; } break;                 \
+    default: throw std::invalid_argument("mvn: unsupported tile width"); \
+  }
+
+
 const char* backend_name() { return "host-emulation (test only)"; }
 
 int device_count() { return 1; }
@@ -83,16 +94,6 @@ float event_elapsed_ms(event_t a, event_t b) {
   return std::chrono::duration<float, std::milli>(((EmuEvent*)b)->t - ((EmuEvent*)a)->t).count();
 }
 
-#define MVN_DISPATCH_T(T_, CALL)                                   \
-  switch (T_) {                                                    \
-    case 16: { constexpr int TT = 16; CALL; } break;               \
-    case 8: { constexpr int TT = 8; CALL; } break;                 \
-    case 4: { constexpr int TT = 4; CALL; } break;                 \
-    case 2: { constexpr int TT = 2; CALL; } break;                 \
-    case 1: { constexpr int TT = 1; CALL; } break;                 \
-    default: throw std::invalid_argument("mvn: unsupported tile width"); \
-  }
-
 // fixed-length kernels: every phase is run for all thread ids in turn (real thread mapping)
 template <int H>
 static void emu_rows_fused(const RowsParams& p, long ntiles) {
@@ -113,7 +114,19 @@ static void emu_rows_fused(const RowsParams& p, long ntiles) {
   }
 }
 
-void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int, size_t, stream_t) {
+void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int, size_t lds_bytes, stream_t) {
+  if (!p.fixed) {  // run-time-radix form of the fused pass (any even d2)
+#pragma omp parallel
+    {
+      std::vector<char> lds(lds_bytes + 64);
+#pragma omp for schedule(static)
+      for (long t = 0; t < ntiles; ++t) {
+        cfloat* l = (cfloat*)lds.data();
+        MVN_DISPATCH_T(p.T, (rows_c2r_even_body<TT, true>(p, t, 0, 1, l)));
+      }
+    }
+    return;
+  }
   switch (p.h) {
 #define X(H) case H: emu_rows_fused<H>(p, ntiles); return;
     MVN_FIXED_ROWS_LENGTHS(X)

@@ -115,9 +115,9 @@ class Plan3D {
                 Profiler* prof = nullptr) const;
   void rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
                 const EpilogueParams& epi, be::stream_t s, Profiler* prof = nullptr) const;
-  // fused c2r + pointwise + r2c (fixed-length plans only, see can_fuse_rows()); in place on
+  // fused c2r + pointwise + r2c (even d2 only, see can_fuse_rows()); in place on
   // (data, nyq); epi.mode is DIVIDE, UPDATE or STORE
-  bool can_fuse_rows() const { return fx_rows; }
+  bool can_fuse_rows() const { return L.even; }
   void rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, be::stream_t s,
                     Profiler* prof = nullptr) const;
   // strided passes on the main array and its Nyquist plane; mode = MvnStridedMode

@@ -475,28 +475,11 @@ MVN_HD void fx_rows_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
 
-MVN_HD float fx_blend(float w, float next, float last) {
-  MVN_FP_EXACT
-  return w * (next - last) + last;
-}
-
-// pair epilogue of the fused pass: the result y = (y[2j], y[2j+1]) is the packed input z[j] of the
-// next forward transform; UPDATE also writes psi.  EPI is the compile-time MvnEpilogue mode: the
-// kernels are instantiated per mode so that a mode's dead operand registers and branches vanish.
+// compile-time-mode form of the fused pass's pair epilogue: the kernels are instantiated per
+// mode so that a mode's dead operand registers and branches vanish
 template <int EPI>
 MVN_HD cfloat fx_epilogue_pair_value(const EpilogueParams& e, long i, cfloat z, cfloat a, cfloat b) {
-  MVN_FP_EXACT
-  const float x0 = z.x * e.scale, x1 = z.y * e.scale;
-  if (EPI == MVN_EPI_DIVIDE)
-    return cmake(mvn_quotient_g(a.x, x0, e.guard_zero_view), mvn_quotient_g(a.y, x1, e.guard_zero_view));
-  if (EPI == MVN_EPI_UPDATE) {
-    const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);
-    const float n1 = mvn_next_value(a.y, x1, e.lambda, e.lambda_inv, e.min_value);
-    const cfloat y = cmake(fx_blend(b.x, n0, a.x), fx_blend(b.y, n1, a.y));
-    *reinterpret_cast<cfloat*>(e.psi + i) = y;
-    return y;
-  }
-  return cmake(x0, x1);
+  return mvn_epilogue_pair_value(EPI, e, i, z, a, b);
 }
 
 // c2r phase 0: spectral rows -> LDS (position order both sides), plus the epilogue operands of the

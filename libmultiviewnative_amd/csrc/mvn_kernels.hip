@@ -52,6 +52,13 @@ __global__ void __launch_bounds__(512) k_rows_c2r(const RowsParams p) {
 }
 
 // NYQ only tags the launches that work on the Nyquist plane, so that profilers list them apart
+// run-time-radix form of the fused c2r + pointwise + r2c pass (any even d2)
+template <int T>
+__global__ void __launch_bounds__(512) k_rows_c2r_r2c(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  rows_c2r_even_body<T, true>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+}
+
 template <int MODE, int T, bool NYQ>
 __global__ void __launch_bounds__(512) k_strided(const StridedParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
@@ -267,6 +274,13 @@ static void check_launch(long nblocks, int nthreads, size_t lds_bytes) {
   if (lds_bytes > 160 * 1024) throw std::invalid_argument("mvn: LDS request exceeds 160 KiB");
 }
 
+template <typename K, typename P>
+static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t lds_bytes, stream_t s) {
+  ensure_lds(kernel, lds_bytes);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(nthreads), lds_bytes, hs(s), p);
+  HIP_CHECK(hipGetLastError());
+}
+
 #define MVN_DISPATCH_T(T_, KERNEL_EXPR)                                        \
   switch (T_) {                                                                \
     case 16: { constexpr int TT = 16; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break; \
@@ -276,13 +290,6 @@ static void check_launch(long nblocks, int nthreads, size_t lds_bytes) {
     case 1: { constexpr int TT = 1; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break;   \
     default: throw std::invalid_argument("mvn: unsupported tile width");       \
   }
-
-template <typename K, typename P>
-static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t lds_bytes, stream_t s) {
-  ensure_lds(kernel, lds_bytes);
-  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(nthreads), lds_bytes, hs(s), p);
-  HIP_CHECK(hipGetLastError());
-}
 
 static void check_aligned16(const void* p, const char* what) {
   if (((size_t)p) & 15) throw std::invalid_argument(std::string("mvn: fixed kernels need 16-byte aligned ") + what);
@@ -339,7 +346,10 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
 void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t lds_bytes,
                          stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
-  if (!p.fixed) throw std::invalid_argument("mvn: the fused rows pass exists for fixed lengths only");
+  if (!p.fixed) {
+    MVN_DISPATCH_T(p.T, (k_rows_c2r_r2c<TT>));
+    return;
+  }
   check_aligned16(p.in_cplx, "input");
   check_aligned16(p.out_cplx, "output");
   switch (p.h) {

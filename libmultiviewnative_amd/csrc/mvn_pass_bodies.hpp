@@ -152,6 +152,29 @@ MVN_HD void mvn_epilogue_pair(const EpilogueParams& e, float* out, long i, cfloa
   }
 }
 
+MVN_HD float mvn_blend(float w, float next, float last) {
+  MVN_FP_EXACT
+  return w * (next - last) + last;  // inc/cpu_kernels.h:51-52
+}
+
+// Pair epilogue of the fused c2r + pointwise + r2c pass: hands the two results back as the packed
+// input z[j] = (y[2j], y[2j+1]) of the next forward transform; UPDATE also writes psi.
+MVN_HD cfloat mvn_epilogue_pair_value(int mode, const EpilogueParams& e, long i, cfloat z, cfloat a,
+                                      cfloat b) {
+  MVN_FP_EXACT
+  const float x0 = z.x * e.scale, x1 = z.y * e.scale;
+  if (mode == MVN_EPI_DIVIDE)
+    return cmake(mvn_quotient_g(a.x, x0, e.guard_zero_view), mvn_quotient_g(a.y, x1, e.guard_zero_view));
+  if (mode == MVN_EPI_UPDATE) {
+    const float n0 = mvn_next_value(a.x, x0, e.lambda, e.lambda_inv, e.min_value);
+    const float n1 = mvn_next_value(a.y, x1, e.lambda, e.lambda_inv, e.min_value);
+    const cfloat y = cmake(mvn_blend(b.x, n0, a.x), mvn_blend(b.y, n1, a.y));
+    *reinterpret_cast<cfloat*>(e.psi + i) = y;
+    return y;
+  }
+  return cmake(x0, x1);
+}
+
 // the same with the mode as a template constant (fixed-length kernels)
 template <int EPI>
 MVN_HD void mvn_epilogue_pair_t(const EpilogueParams& e, float* out, long i, cfloat z, cfloat a,
@@ -188,6 +211,40 @@ struct RowsParams {
   EpilogueParams epi;
 };
 
+// forward stages + real<->complex step + store of a tile that already sits in LDS as the packed
+// rows z[j] (shared by the plain r2c pass and the fused c2r + pointwise + r2c pass)
+template <int T>
+MVN_HD void rows_r2c_even_tail(const RowsParams& P, long r0, cfloat*& buf, cfloat*& alt,
+                               const cfloat* tw, int tid, int nthreads) {
+  const int h = P.h, TP = P.TP;
+  lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
+  const int npairs = h / 2 + 1;
+  for (int w = tid; w < npairs * T; w += nthreads) {
+    const int k = w / T, rho = w - k * T;
+    const int m = (h - k) % h;
+    const int pk = P.ax.inv[k], pm = P.ax.inv[m];
+    const cfloat zk = buf[pk * TP + rho];
+    if (k == 0) {
+      buf[pk * TP + rho] = cmake(zk.x + zk.y, 0.f);
+      if (r0 + rho < P.rows) P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);
+    } else {
+      const cfloat zm = buf[pm * TP + rho];
+      const cfloat E = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+      const cfloat D = cmake(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+      const cfloat G = cmul(P.twr[k], D);
+      buf[pk * TP + rho] = cadd(E, cmul_si<-1>(G));
+      if (m != k) buf[pm * TP + rho] = cadd(cconj(E), cmul_si<-1>(cconj(G)));
+    }
+  }
+  MVN_SYNC();
+  for (int w = tid; w < T * h; w += nthreads) {
+    // spectral rows are kept in position (digit-reversed) order: bin k sits at column inv[k]
+    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), p = w - rho * h;
+    const long row = r0 + rho;
+    if (row < P.rows) P.out_cplx[row * P.C + p] = buf[p * TP + rho];
+  }
+}
+
 // real -> half-complex, even d2: z[j] = x[2j] + i x[2j+1], Z = FFT_h(z), then
 // X[k] = E - i w^k D,  E = (Z[k] + conj Z[h-k])/2,  D = (Z[k] - conj Z[h-k])/2,  w = exp(-2 pi i/d2)
 template <int T>
@@ -222,37 +279,14 @@ MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthr
     }
   }
   MVN_SYNC();
-  lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
-  const int npairs = h / 2 + 1;
-  for (int w = tid; w < npairs * T; w += nthreads) {
-    const int k = w / T, rho = w - k * T;
-    const int m = (h - k) % h;
-    const int pk = P.ax.inv[k], pm = P.ax.inv[m];
-    const cfloat zk = buf[pk * TP + rho];
-    if (k == 0) {
-      buf[pk * TP + rho] = cmake(zk.x + zk.y, 0.f);
-      if (r0 + rho < P.rows) P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);
-    } else {
-      const cfloat zm = buf[pm * TP + rho];
-      const cfloat E = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-      const cfloat D = cmake(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-      const cfloat G = cmul(P.twr[k], D);
-      buf[pk * TP + rho] = cadd(E, cmul_si<-1>(G));
-      if (m != k) buf[pm * TP + rho] = cadd(cconj(E), cmul_si<-1>(cconj(G)));
-    }
-  }
-  MVN_SYNC();
-  for (int w = tid; w < T * h; w += nthreads) {
-    // spectral rows are kept in position (digit-reversed) order: bin k sits at column inv[k]
-    const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), p = w - rho * h;
-    const long row = r0 + rho;
-    if (row < P.rows) P.out_cplx[row * P.C + p] = buf[p * TP + rho];
-  }
+  rows_r2c_even_tail<T>(P, r0, buf, alt, tw, tid, nthreads);
 }
 
 // half-complex -> real, even d2: Z[k] = E + i O, E = X[k] + conj X[h-k],
 // O = (X[k] - conj X[h-k]) exp(+2 pi i k/d2); z = IFFT_h(Z); x[2j] = Re z[j], x[2j+1] = Im z[j]
-template <int T>
+// KEEP = true is the fused pass: the epilogue results stay in LDS and run straight through the
+// forward half (rows_r2c_even_tail), writing the half-spectrum of the result over the input.
+template <int T, bool KEEP = false>
 MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
   constexpr int U = MVN_ROWS_U;
   const int h = P.h, TP = P.TP;
@@ -335,9 +369,18 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
       const int w = w0 + u * nthreads;
       const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)h, P.hmul), j = w - rho * h;
       const long row = r0 + rho;
-      if (w < total && row <= last_row)
-        mvn_epilogue_pair(P.epi, P.out_real, row * P.RP + 2 * j, buf[j * TP + rho], ea[u], eb[u]);
+      if (w < total && row <= last_row) {
+        if (KEEP)
+          buf[j * TP + rho] = mvn_epilogue_pair_value(P.epi.mode, P.epi, row * P.RP + 2 * j,
+                                                      buf[j * TP + rho], ea[u], eb[u]);
+        else
+          mvn_epilogue_pair(P.epi, P.out_real, row * P.RP + 2 * j, buf[j * TP + rho], ea[u], eb[u]);
+      }
     }
+  }
+  if (KEEP) {
+    MVN_SYNC();
+    rows_r2c_even_tail<T>(P, r0, buf, alt, tw, tid, nthreads);
   }
 }
 

@@ -210,9 +210,12 @@ MVN_HD void fx_copy_table(cfloat* dst, const cfloat* src, int count, int tid) {
 // ---------------------------------------------------------------------------------------------
 // strided-axis pass, full tiles of T neighbouring bins (cstride == 1, ncols % T == 0)
 // ---------------------------------------------------------------------------------------------
+#ifndef MVN_FX_STRIDED_T
+#define MVN_FX_STRIDED_T 16
+#endif
 template <int N>
 struct FxStridedCfg {
-  static constexpr int T = N <= 512 ? 16 : 8;
+  static constexpr int T = N <= 512 ? MVN_FX_STRIDED_T : 8;
   static constexpr int TP = T;
   static constexpr int CH = T / 2;  // 16-byte chunks per tile row
   static constexpr int NTfull = N * T / 8;

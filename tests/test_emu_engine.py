@@ -291,3 +291,11 @@ def test_zero_padd_good_size_mode(emu, monkeypatch):
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
     # the closed form of the synthetic data holds in the interior (constant views, delta PSFs)
     assert abs(float(got[9, 6, 8]) - 30.0 * (np.sqrt(1 + 2 * 0.006 * 30.0) - 1) / (0.006 * 30.0)) < 1e-2
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.006])
+def test_golden_rl_small(emu, lam):
+    from golden_util import rl_small
+    psi0, h, seq, _ = rl_small(lam)
+    got = emu.gpu_deconvolve(psi0, h)
+    assert np.abs(got - seq).max() <= 1e-4 * np.abs(seq).max()

@@ -560,3 +560,34 @@ def test_degenerate_inputs(gpu, capfd):
     got = gpu.gpu_deconvolve(np.ones(thin, np.float32), hh)
     ref = orc2.cpu_deconvolve(np.ones(thin, np.float32), hh, 1)
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", ["identity", "horizont", "vertical", "depth", "all1"])
+def test_golden_fixture_a(gpu, name):
+    # committed golden vectors (tests/golden/fixture_a.npz): the reference's fixture and its
+    # FFT-independent expectations
+    from golden_util import fixture_a
+    g = fixture_a()
+    out = gpu.gpu_convolution(g["padded_image"], g["kernel_" + name])[1:9, 1:9, 1:9]
+    want = g["expect_" + name]
+    assert np.abs(out - want).max() <= 3e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.006])
+def test_golden_rl_small(gpu, lam):
+    # committed RL vectors computed by the float64 numpy restatement (independent of the C oracle)
+    from golden_util import rl_small
+    psi0, h, seq, sim = rl_small(lam)
+    got = gpu.gpu_deconvolve(psi0, h)
+    assert np.abs(got - seq).max() <= MAX_REL * np.abs(seq).max()
+    nv = h.ws.num_views_
+    eng = gpu.engine(psi0.shape, nv)
+    for v in range(nv):
+        eng.set_view(v, h.views[v], h.weights[v], h.kernels1[v], h.kernels2[v])
+    eng.set_psi(psi0)
+    for _ in range(h.ws.num_iterations_):
+        eng.compute_delta(lam, 1e-4)
+        eng.apply_delta()
+    got = eng.get_psi()
+    eng.close()
+    assert np.abs(got - sim).max() <= MAX_REL * np.abs(sim).max()

@@ -66,25 +66,33 @@ struct FxCtx {
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// compile-time plan of a power-of-two length: same radix order as AxisPlanHost::factorize
+// compile-time plan of a length 2^a 3^b 5^c 7^d: same radix order as AxisPlanHost::factorize
 // ---------------------------------------------------------------------------------------------
 constexpr bool fx_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+constexpr bool fx_smooth(int n) {  // only the factors the register butterflies cover
+  if (n < 1) return false;
+  for (int p : {2, 3, 5, 7})
+    while (n % p == 0) n /= p;
+  return n == 1;
+}
+
 constexpr int fx_nstages(int n) {
   int c = 0;
-  while (n % 8 == 0) { n /= 8; ++c; }
-  while (n % 4 == 0) { n /= 4; ++c; }
-  while (n % 2 == 0) { n /= 2; ++c; }
+  for (int r : {8, 4, 2, 3, 5, 7})
+    while (n % r == 0) { n /= r; ++c; }
   return c;
 }
 
 constexpr int fx_radix(int n, int s) {
   int c = 0;
-  while (n % 8 == 0) { if (c == s) return 8; n /= 8; ++c; }
-  while (n % 4 == 0) { if (c == s) return 4; n /= 4; ++c; }
-  while (n % 2 == 0) { if (c == s) return 2; n /= 2; ++c; }
+  for (int r : {8, 4, 2, 3, 5, 7})
+    while (n % r == 0) { if (c == s) return r; n /= r; ++c; }
   return 1;
 }
+
+// twiddle rows are padded to an even number of entries so that they stay 16-byte aligned
+constexpr int fx_rs(int r) { return r + (r & 1); }
 
 constexpr int fx_M(int n, int s) {  // butterfly input stride of stage s
   int m = n;
@@ -98,12 +106,12 @@ constexpr int fx_W(int n, int s) {  // weight of digit s in the natural index
   return w;
 }
 
-// stage-ordered twiddle table: for every stage with M > 1 a block of M rows of R entries,
-// row j2 = { exp(-2 pi i j2 k / (R M)) : k = 0..R-1 }
+// stage-ordered twiddle table: for every stage with M > 1 a block of M rows of fx_rs(R) entries,
+// row j2 = { exp(-2 pi i j2 k / (R M)) : k = 0..R-1 } (+ one pad entry for odd R)
 constexpr int fx_twoff(int n, int s) {
   int off = 0;
   for (int t = 0; t < s; ++t)
-    if (fx_M(n, t) > 1) off += fx_M(n, t) * fx_radix(n, t);
+    if (fx_M(n, t) > 1) off += fx_M(n, t) * fx_rs(fx_radix(n, t));
   return off;
 }
 constexpr int fx_twsize(int n) { return fx_twoff(n, fx_nstages(n)); }
@@ -154,11 +162,11 @@ MVN_HD void fx_stage(cfloat* buf, const cfloat* tws, int tid) {
     cfloat a[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) a[j] = p[fx_rowoff<PAD, R, M>(j) * TP];
-    cfloat tw[R];
+    cfloat tw[fx_rs(R)];
     if (M > 1) {
-      const qfloat* t4 = reinterpret_cast<const qfloat*>(tws + fx_twoff(N, S) + j2 * R);
+      const qfloat* t4 = reinterpret_cast<const qfloat*>(tws + fx_twoff(N, S) + j2 * fx_rs(R));
 #pragma unroll
-      for (int k = 0; k < R / 2; ++k) {
+      for (int k = 0; k < fx_rs(R) / 2; ++k) {
         const qfloat t = t4[k];
         tw[2 * k] = cmake(t.x, t.y);
         tw[2 * k + 1] = cmake(t.z, t.w);
@@ -210,21 +218,29 @@ MVN_HD void fx_copy_table(cfloat* dst, const cfloat* src, int count, int tid) {
 // ---------------------------------------------------------------------------------------------
 // strided-axis pass, full tiles of T neighbouring bins (cstride == 1, ncols % T == 0)
 // ---------------------------------------------------------------------------------------------
-#ifndef MVN_FX_STRIDED_T
-#define MVN_FX_STRIDED_T 16
-#endif
+// largest multiple of 64 that is <= min(cap, full) and divides a, b and c (0 if none)
+constexpr int fx_pick_nt(int cap, int full, int a, int b, int c) {
+  for (int nt = cap; nt >= 64; nt -= 64)
+    if (nt <= full && a % nt == 0 && b % nt == 0 && c % nt == 0) return nt;
+  return 0;
+}
+
 template <int N>
 struct FxStridedCfg {
-  static constexpr int T = N <= 512 ? MVN_FX_STRIDED_T : 8;
+  static constexpr int T = N <= 576 ? 16 : 8;  // tile + twiddles <= 80 KB (two workgroups per CU) up to 576
   static constexpr int TP = T;
   static constexpr int CH = T / 2;  // 16-byte chunks per tile row
-  static constexpr int NTfull = N * T / 8;
-  static constexpr int NT = NTfull >= 512 ? 512 : (NTfull >= 64 ? NTfull : 64);
+  // threads: whole tile rows per sweep (N * CH divisible by NT), not more than one radix-8
+  // butterfly each; 512 unless that leaves more than eight 16-byte loads per thread (long axes)
+  static constexpr int FULL = N * T / 8 >= 64 ? N * T / 8 : 64;
+  static constexpr int NT512 = fx_pick_nt(512, FULL, N * CH, N * CH, N * CH);
+  static constexpr int NT = (NT512 > 0 && N * CH / NT512 <= 8) ? NT512 : fx_pick_nt(1024, FULL, N * CH, N * CH, N * CH);
   static constexpr int RPT = NT / CH;      // tile rows covered by one sweep of the workgroup
   static constexpr int U = N / RPT;        // 16-byte loads per thread
   static constexpr int lds_cfloats = N * TP + fx_twsize(N);
-  static_assert(fx_pow2(N) && N >= 64 && N <= 1024, "unsupported fixed length");
-  static_assert(N % RPT == 0, "tile rows must divide");
+  static_assert(fx_smooth(N) && N >= 64 && N <= 2048, "unsupported fixed length");
+  static_assert(NT >= 64 && N % RPT == 0, "tile rows must divide");
+  static_assert(sizeof(cfloat) * lds_cfloats <= 160 * 1024, "tile does not fit the LDS");
 };
 
 template <int N>
@@ -321,30 +337,31 @@ MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx
 //   c2r+r2c fused: ... last inverse stage -> epilogue -> first forward stage ... all in registers
 // The remaining stages use the column-fastest mapping of fx_stage.
 // ---------------------------------------------------------------------------------------------
-#ifndef MVN_FX_ROWS_T
-#define MVN_FX_ROWS_T 16
-#endif
 template <int H>
 struct FxRowsCfg {
-  static constexpr int T = H <= 512 ? MVN_FX_ROWS_T : 8;
+  static constexpr bool PAD = fx_pow2(H);  // the spare-row trick relies on power-of-two block sizes
+  static constexpr int T = H <= 512 ? 16 : 8;
   static constexpr int TP = T + 1;
   static constexpr int QR = H / 2;  // 16-byte chunks per spectral row (2 complex bins each)
-  static constexpr int NTfull = H * T / 8;
-  static constexpr int NT = NTfull >= 512 ? 512 : (NTfull >= 64 ? NTfull : 64);
-  static constexpr int U = T * QR / NT;  // 16-byte spectral loads/stores per thread
   static constexpr int R0 = fx_radix(H, 0);
   static constexpr int M0 = fx_M(H, 0);
-  static constexpr int IT0 = (M0 * T) / NT;  // stage-0 butterflies per thread
-  static constexpr int ROWS = fx_rows_alloc(H, true);
+  // threads: one stage-0 butterfly each where possible (up to 1024 per workgroup), dividing the
+  // 16-byte row chunks, the stage-0 butterflies and the bin pairs evenly
+#ifndef MVN_FX_ROWS_NT_CAP
+#define MVN_FX_ROWS_NT_CAP 1024
+#endif
+  static constexpr int NT = fx_pick_nt(MVN_FX_ROWS_NT_CAP, H * T / 8 >= 64 ? H * T / 8 : 64, T * QR, M0 * T, H / 2 * T);
+  static constexpr int U = T * QR / (NT > 0 ? NT : 1);   // 16-byte spectral loads/stores per thread
+  static constexpr int IT0 = (M0 * T) / (NT > 0 ? NT : 1);  // stage-0 butterflies per thread
+  static constexpr int ROWS = fx_rows_alloc(H, PAD);
   static constexpr int TILE = (ROWS * TP + 1) & ~1;  // keeps the tables behind it 16-byte aligned
   // tile | stage twiddles | d2-th roots (H/2+1, padded to even) | pair table (H/2 entries of 2 ints)
   static constexpr int TWR = (H / 2 + 2) & ~1;
   static constexpr int lds_cfloats = TILE + fx_twsize(H) + TWR + H / 2;
-  static constexpr int ITP = (H / 2 * T) / NT;  // bin pairs per thread in the real<->complex step
-  static_assert((H / 2 * T) % NT == 0, "pair step must divide");
-  static_assert(fx_pow2(H) && H >= 32 && H <= 1024, "unsupported fixed length");
-  static_assert((T * QR) % NT == 0, "tile must divide");
-  static_assert((M0 * T) % NT == 0 && IT0 >= 1 && R0 == 8, "stage 0: whole radix-8 butterflies per thread");
+  static constexpr int ITP = (H / 2 * T) / (NT > 0 ? NT : 1);  // bin pairs per thread in the real<->complex step
+  static_assert(fx_smooth(H) && H % 2 == 0 && H >= 32 && H <= 1024, "unsupported fixed length");
+  static_assert(NT >= 64 && R0 == 8, "stage 0: whole radix-8 butterflies per thread");
+  static_assert(sizeof(cfloat) * lds_cfloats <= 160 * 1024, "tile does not fit the LDS");
 };
 
 template <int H>
@@ -367,8 +384,8 @@ MVN_HD void fx_build_pair_table(FxPair* tab, int tid) {
   typedef FxRowsCfg<H> C;
   for (int k = tid; k < H / 2; k += C::NT) {
     FxPair e;
-    e.a = fx_row<true>(fx_inv<H>(k)) * C::TP;
-    e.b = fx_row<true>(fx_inv<H>(k == 0 ? H / 2 : H - k)) * C::TP;
+    e.a = fx_row<C::PAD>(fx_inv<H>(k)) * C::TP;
+    e.b = fx_row<C::PAD>(fx_inv<H>(k == 0 ? H / 2 : H - k)) * C::TP;
     tab[k] = e;
   }
 }
@@ -378,7 +395,7 @@ template <int R>
 MVN_HD void fx_load_tw_row(const cfloat* row, cfloat* tw) {
   const qfloat* t4 = reinterpret_cast<const qfloat*>(row);
 #pragma unroll
-  for (int k = 0; k < R / 2; ++k) {
+  for (int k = 0; k < fx_rs(R) / 2; ++k) {
     const qfloat t = t4[k];
     tw[2 * k] = cmake(t.x, t.y);
     tw[2 * k + 1] = cmake(t.z, t.w);
@@ -407,14 +424,14 @@ MVN_HD void fx_r2c_load_stage0(const RowsParams& P, long r0, cfloat* buf, cfloat
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * NT;
     const int j2 = w % M, rho = w / M;
-    cfloat tw[R];
-    fx_load_tw_row<R>(P.ax.tws + j2 * R, tw);  // stage 0 opens the table; the LDS copy is not ready yet
+    cfloat tw[fx_rs(R)];
+    fx_load_tw_row<R>(P.ax.tws + j2 * fx_rs(R), tw);  // stage 0 opens the table; the LDS copy is not ready yet
     dftR<R, -1>(a[it]);
 #pragma unroll
     for (int k = 1; k < R; ++k) a[it][k] = cmul(a[it][k], tw[k]);
-    cfloat* p = buf + fx_row<true>(j2) * TP + rho;
+    cfloat* p = buf + fx_row<C::PAD>(j2) * TP + rho;
 #pragma unroll
-    for (int k = 0; k < R; ++k) p[fx_rowoff<true, R, M>(k) * TP] = a[it][k];
+    for (int k = 0; k < R; ++k) p[fx_rowoff<C::PAD, R, M>(k) * TP] = a[it][k];
   }
 }
 
@@ -457,8 +474,8 @@ MVN_HD void fx_r2c_store(const RowsParams& P, long r0, const cfloat* buf, int ti
     const int e = tid + u * NT;
     const int rho = e / C::QR, kk = e % C::QR;
     // spectral rows are kept in position (digit-reversed) order: bin k sits at column inv(k)
-    const cfloat a = buf[fx_row<true>(2 * kk) * TP + rho];
-    const cfloat b = buf[fx_row<true>(2 * kk + 1) * TP + rho];
+    const cfloat a = buf[fx_row<C::PAD>(2 * kk) * TP + rho];
+    const cfloat b = buf[fx_row<C::PAD>(2 * kk + 1) * TP + rho];
     reinterpret_cast<qfloat*>(P.out_cplx + (r0 + rho) * P.C)[kk] = qmake(a.x, a.y, b.x, b.y);
   }
 }
@@ -473,7 +490,7 @@ MVN_HD void fx_rows_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_r2c_load_stage0<H>(P, r0, buf, tws, twr, tid)));
-  fx_dif<H, T, TP, true, NT, -1, 1>(buf, tws, ctx);
+  fx_dif<H, T, TP, C::PAD, NT, -1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
@@ -526,8 +543,8 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
     const int rho = e / C::QR, kk = e % C::QR;
-    buf[fx_row<true>(2 * kk) * TP + rho] = cmake(r.v[u].x, r.v[u].y);
-    buf[fx_row<true>(2 * kk + 1) * TP + rho] = cmake(r.v[u].z, r.v[u].w);
+    buf[fx_row<C::PAD>(2 * kk) * TP + rho] = cmake(r.v[u].x, r.v[u].y);
+    buf[fx_row<C::PAD>(2 * kk + 1) * TP + rho] = cmake(r.v[u].z, r.v[u].w);
   }
 }
 
@@ -574,12 +591,12 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * NT;
     const int j2 = w % M, rho = w / M;
-    cfloat* p = buf + fx_row<true>(j2) * TP + rho;
+    cfloat* p = buf + fx_row<C::PAD>(j2) * TP + rho;
     cfloat a[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) a[k] = p[fx_rowoff<true, R, M>(k) * TP];
-    cfloat tw[R];
-    fx_load_tw_row<R>(tws + j2 * R, tw);
+    for (int k = 0; k < R; ++k) a[k] = p[fx_rowoff<C::PAD, R, M>(k) * TP];
+    cfloat tw[fx_rs(R)];
+    fx_load_tw_row<R>(tws + j2 * fx_rs(R), tw);
 #pragma unroll
     for (int k = 1; k < R; ++k) a[k] = cmul(a[k], cconj(tw[k]));
     dftR<R, +1>(a);  // a[jo] = z[j2 + M*jo] = (x[2j], x[2j+1])
@@ -592,7 +609,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
 #pragma unroll
       for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[k]);
 #pragma unroll
-      for (int k = 0; k < R; ++k) p[fx_rowoff<true, R, M>(k) * TP] = a[k];
+      for (int k = 0; k < R; ++k) p[fx_rowoff<C::PAD, R, M>(k) * TP] = a[k];
     } else {
 #pragma unroll
       for (int jo = 0; jo < R; ++jo)
@@ -616,9 +633,9 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
-  fx_dit<H, T, TP, true, NT, +1, 1>(buf, tws, ctx);
+  fx_dit<H, T, TP, C::PAD, NT, +1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, true, EPI>(P, r0, buf, tws, r, tid)));
-  fx_dif<H, T, TP, true, NT, -1, 1>(buf, tws, ctx);
+  fx_dif<H, T, TP, C::PAD, NT, -1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
@@ -634,6 +651,6 @@ MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
-  fx_dit<H, T, TP, true, NT, +1, 1>(buf, tws, ctx);
+  fx_dit<H, T, TP, C::PAD, NT, +1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, false, EPI>(P, r0, buf, tws, r, tid)));
 }

@@ -270,7 +270,7 @@ static void ensure_lds(K kernel, size_t lds_bytes) {
 
 static void check_launch(long nblocks, int nthreads, size_t lds_bytes) {
   if (nblocks < 1 || nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
-  if (nthreads < 64 || nthreads > 512 || nthreads % 64) throw std::invalid_argument("mvn: bad block size");
+  if (nthreads < 64 || nthreads > 1024 || nthreads % 64) throw std::invalid_argument("mvn: bad block size");
   if (lds_bytes > 160 * 1024) throw std::invalid_argument("mvn: LDS request exceeds 160 KiB");
 }
 

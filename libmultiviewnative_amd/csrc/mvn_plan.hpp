@@ -70,7 +70,7 @@ struct AxisPlanHost {
     for (size_t s = 0; s < radix.size(); ++s) {
       if (M[s] <= 1) continue;
       const int R = radix[s], L = R * M[s];
-      for (int j2 = 0; j2 < M[s]; ++j2)
+      for (int j2 = 0; j2 < M[s]; ++j2) {
         for (int k = 0; k < R; ++k) {
           double a = -2.0 * M_PI * (double)((long)j2 * k % L) / (double)L;
           cfloat w;
@@ -78,6 +78,13 @@ struct AxisPlanHost {
           w.y = (float)std::sin(a);
           tws.push_back(w);
         }
+        if (R & 1) {  // rows are padded to an even number of entries (16-byte alignment)
+          cfloat z;
+          z.x = 0.f;
+          z.y = 0.f;
+          tws.push_back(z);
+        }
+      }
     }
     rev.resize(n);
     inv.resize(n);

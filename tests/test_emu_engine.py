@@ -45,6 +45,36 @@ def test_fixed_kernels_roundtrip_and_forward(emu, shape):
     assert np.abs(back - x).max() < 1e-5
 
 
+# mixed-radix (2^a 3^b 5^c) lengths served by the compile-time kernels: (fx_rows, fx_ax1, fx_ax0)
+MIXED_FIXED_SHAPES = {(64, 192, 384): (1, 1, 1), (320, 64, 640): (1, 1, 1), (64, 576, 192): (1, 1, 1),
+                      (2, 1920, 1920): (1, 1, 0), (1280, 16, 64): (1, 0, 1), (960, 16, 576): (1, 0, 1),
+                      (768, 16, 960): (1, 0, 1), (640, 384, 64): (1, 1, 1), (16, 64, 1536): (1, 1, 0),
+                      (16, 64, 1280): (1, 1, 0)}
+
+
+@pytest.mark.parametrize("shape", sorted(MIXED_FIXED_SHAPES))
+def test_mixed_radix_fixed_kernels(emu, shape):
+    info = emu.plan_describe(shape)
+    assert (info["fx_rows"], info["fx_ax1"], info["fx_ax0"]) == MIXED_FIXED_SHAPES[shape]
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = emu.rfft3(x)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
+    back = emu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 2e-5
+
+
+def test_mixed_radix_fixed_deconvolve_vs_oracle(emu):
+    shape = (64, 192, 320)
+    assert emu.plan_describe(shape)["fx_rows"] == 1
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 7, 9))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    got = emu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, 8)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 def test_fixed_kernels_deconvolve_vs_oracle(emu):
     shape = (64, 64, 128)
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 7, 9))

@@ -96,6 +96,33 @@ def test_fixed_kernels_forward_and_roundtrip(gpu, shape):
     assert np.abs(back - x).max() < 2e-5
 
 
+MIXED_FIXED_SHAPES = {(64, 192, 384): (1, 1, 1), (320, 64, 640): (1, 1, 1), (64, 576, 192): (1, 1, 1),
+                      (2, 1920, 1920): (1, 1, 0), (1280, 16, 64): (1, 0, 1), (960, 16, 576): (1, 0, 1),
+                      (768, 16, 960): (1, 0, 1), (640, 384, 64): (1, 1, 1), (16, 64, 1536): (1, 1, 0),
+                      (16, 64, 1280): (1, 1, 0)}
+
+
+@pytest.mark.parametrize("shape", sorted(MIXED_FIXED_SHAPES))
+def test_mixed_radix_fixed_kernels(gpu, shape):
+    info = gpu.plan_describe(shape)
+    assert (info["fx_rows"], info["fx_ax1"], info["fx_ax0"]) == MIXED_FIXED_SHAPES[shape]
+    x = np.random.default_rng(10).standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = gpu.rfft3(x)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
+    back = gpu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 2e-5
+
+
+def test_mixed_radix_fixed_deconvolve_vs_oracle(gpu, orc):
+    shape = (64, 192, 320)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 7, 9))
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+        mx, rms = rel_err(gpu.gpu_deconvolve(psi0, h), orc.cpu_deconvolve(psi0, h, 8))
+        assert mx <= MAX_REL and rms <= RMS_REL
+
+
 def test_fixed_and_generic_kernels_agree(gpu, orc, monkeypatch):
     # the same shape through the run-time-radix kernels (MVN_NO_FIXED=1) and the specialised ones
     shape = (64, 64, 128)

@@ -227,7 +227,9 @@ constexpr int fx_pick_nt(int cap, int full, int a, int b, int c) {
 
 template <int N>
 struct FxStridedCfg {
-  static constexpr int T = N <= 576 ? 16 : 8;  // tile + twiddles <= 80 KB (two workgroups per CU) up to 576
+  // 128-byte row segments wherever the tile fits the LDS at all (two workgroups per CU up to
+  // N = 576, one beyond; measured: 64-byte segments cost 15-30 % of the pass at N = 640..1024)
+  static constexpr int T = N <= 1024 ? 16 : 8;
   static constexpr int TP = T;
   static constexpr int CH = T / 2;  // 16-byte chunks per tile row
   // threads: whole tile rows per sweep (N * CH divisible by NT), not more than one radix-8

@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--views-per-gpu", type=int, default=6)
     ap.add_argument("--psf", type=int, default=31)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
+                    help="BASELINE.json configs[i]: 1 = 256^3 x 1 view x 15^3 PSF, 2 = 512^3 x 6 views x 31^3 "
+                         "(default, the headline), 4 = 320x1920x1920 x 6 views x 31^3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel events in the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -124,6 +127,10 @@ def main():
                     help="skip ms_per_fft and the small parity case (keeps rocprof --stats averages clean)")
     args = ap.parse_args()
 
+    if args.config == 1:
+        args.size, args.views_per_gpu, args.psf = [256, 256, 256], 1, 15
+    elif args.config == 4:
+        args.size, args.views_per_gpu, args.psf = [320, 1920, 1920], 6, 31
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

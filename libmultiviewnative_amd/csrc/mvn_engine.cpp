@@ -90,18 +90,21 @@ struct ProfScope {
 // DevAxis / Plan3D
 // ---------------------------------------------------------------------------------------------
 DevAxis::DevAxis(int n) : host(n) {
-  tw = (cfloat*)be::dmalloc(sizeof(cfloat) * (size_t)n);
-  rev = (int*)be::dmalloc(sizeof(int) * (size_t)n);
-  inv = (int*)be::dmalloc(sizeof(int) * (size_t)n);
-  be::h2d(tw, host.tw.data(), sizeof(cfloat) * (size_t)n, nullptr);
-  if (!host.tws.empty()) {
-    tws = (cfloat*)be::dmalloc(sizeof(cfloat) * host.tws.size());
-    be::h2d(tws, host.tws.data(), sizeof(cfloat) * host.tws.size(), nullptr);
+  auto upload = [](const void* src, size_t bytes) -> void* {
+    void* d = be::dmalloc(bytes);
+    be::h2d(d, src, bytes, nullptr);
+    return d;
+  };
+  tw = (cfloat*)upload(host.tw.data(), sizeof(cfloat) * host.tw.size());  // nfft entries
+  rev = (int*)upload(host.rev.data(), sizeof(int) * host.rev.size());
+  inv = (int*)upload(host.inv.data(), sizeof(int) * host.inv.size());
+  if (!host.tws.empty()) tws = (cfloat*)upload(host.tws.data(), sizeof(cfloat) * host.tws.size());
+  if (host.bluestein) {
+    chirp = (cfloat*)upload(host.chirp.data(), sizeof(cfloat) * host.chirp.size());
+    bhat = (cfloat*)upload(host.bhat.data(), sizeof(cfloat) * host.bhat.size());
   }
-  be::h2d(rev, host.rev.data(), sizeof(int) * (size_t)n, nullptr);
-  be::h2d(inv, host.inv.data(), sizeof(int) * (size_t)n, nullptr);
   be::stream_sync(nullptr);
-  view = host.view(tw, rev, inv, tws);
+  view = host.view(tw, rev, inv, tws, chirp, bhat);
 }
 
 DevAxis::~DevAxis() {
@@ -109,6 +112,8 @@ DevAxis::~DevAxis() {
   be::dfree(tws);
   be::dfree(rev);
   be::dfree(inv);
+  be::dfree(chirp);
+  be::dfree(bhat);
 }
 
 // tuning knobs for experiments (not part of the ABI): MVN_T_ROWS / MVN_T_AXIS / MVN_T_FUSED cap
@@ -179,12 +184,13 @@ Plan3D::Plan3D(int dev, int d0, int d1, int d2)
     be::h2d(twr, roots.data(), sizeof(cfloat) * roots.size(), nullptr);
     be::stream_sync(nullptr);
   }
-  g_rows = pick_geom(L.h, ax2.host.generic, true, env_int("MVN_T_ROWS", 16));
-  g_ax1 = pick_geom(d1, ax1.host.generic, false, env_int("MVN_T_AXIS", 16));
-  g_ax0 = pick_geom(d0, ax0.host.generic, false, env_int("MVN_T_AXIS", 16));
+  // LDS rows per tile = length of the radix transform (the chirp-z length for bluestein axes)
+  g_rows = pick_geom(ax2.host.nfft, ax2.host.generic, true, env_int("MVN_T_ROWS", 16));
+  g_ax1 = pick_geom(ax1.host.nfft, ax1.host.generic, false, env_int("MVN_T_AXIS", 16));
+  g_ax0 = pick_geom(ax0.host.nfft, ax0.host.generic, false, env_int("MVN_T_AXIS", 16));
   // the fused pass has its own geometry so that it can be tuned apart (measured on MI355X at
   // 512^3: T=16 0.46 ms, T=8 0.63 ms)
-  g_ax0f = pick_geom(d0, ax0.host.generic, false, env_int("MVN_T_FUSED", 16));
+  g_ax0f = pick_geom(ax0.host.nfft, ax0.host.generic, false, env_int("MVN_T_FUSED", 16));
   g_nyq1 = g_ax1;
   g_nyq0 = g_ax0;
   // fixed-length fast path: power-of-two line, full tiles, 16-byte aligned rows

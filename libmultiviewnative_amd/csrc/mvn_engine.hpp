@@ -64,6 +64,8 @@ struct DevAxis {
   AxisPlanHost host;
   cfloat* tw = nullptr;
   cfloat* tws = nullptr;
+  cfloat* chirp = nullptr;  // bluestein axes only
+  cfloat* bhat = nullptr;
   int* rev = nullptr;
   int* inv = nullptr;
   AxisPlan view;

@@ -41,7 +41,10 @@ struct cfloat {
 
 // Per-axis plan as the kernels see it (tables live in device memory; see mvn_plan.hpp).
 struct AxisPlan {
-  int n;        // transform length
+  int n;        // transform length (number of rows of a tile)
+  int nfft;     // length the radix stages run on: n, or the chirp-z length m >= 2n-1 (bluestein)
+  int bluestein;  // 1: n has a prime factor the radix stages should not take on (> 31); the
+                  // length-n DFT is then computed as a length-nfft cyclic convolution with a chirp
   int nstages;  // number of radix stages
   int generic;  // 1 if some radix is not one of {2,3,4,5,7,8} (needs the second LDS buffer)
   int radix[MVN_MAX_STAGES];  // DIF order, outermost first
@@ -50,6 +53,8 @@ struct AxisPlan {
   unsigned nmul;                  // same for n
   const cfloat* tw;           // tw[j] = exp(-2 pi i j / n)
   const cfloat* tws;          // stage-ordered twiddles of the fixed-length kernels (mvn_fixed.hpp)
+  const cfloat* chirp;        // bluestein: chirp[j] = exp(-i pi j^2 / n), j < n
+  const cfloat* bhat;         // bluestein: FFT_nfft(conj chirp, wrapped) / nfft, in position order
   const int* rev;             // rev[p] = k : after DIF, position p holds X[k]
   const int* inv;             // inv[k] = p
 };
@@ -282,14 +287,14 @@ MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& p
   const int M = pl.M[s];
   const unsigned mm = pl.Mmul[s];
   switch (R) {
-    case 2: stage_inplace<2, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
-    case 3: stage_inplace<3, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
-    case 4: stage_inplace<4, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
-    case 5: stage_inplace<5, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
-    case 7: stage_inplace<7, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
-    case 8: stage_inplace<8, SIGN, DIF, T>(buf, TP, pl.n, M, mm, tw, tid, nthreads); break;
+    case 2: stage_inplace<2, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 3: stage_inplace<3, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 4: stage_inplace<4, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 5: stage_inplace<5, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 7: stage_inplace<7, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 8: stage_inplace<8, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     default: {
-      stage_generic<SIGN, DIF, T>(buf, alt, TP, pl.n, R, M, tw, tid, nthreads);
+      stage_generic<SIGN, DIF, T>(buf, alt, TP, pl.nfft, R, M, tw, tid, nthreads);
       cfloat* t = buf;
       buf = alt;
       alt = t;
@@ -302,8 +307,8 @@ MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& p
 // have synchronised the tile before the call; the tile is synchronised on return.  `tw` may
 // point to an LDS copy of the plan's twiddle table.
 template <int SIGN, int T>
-MVN_HD void lds_fft_dif(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
-                        int tid, int nthreads) {
+MVN_HD void lds_radix_dif(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
+                          int tid, int nthreads) {
   for (int s = 0; s < pl.nstages; ++s) {
     stage_dispatch<SIGN, true, T>(buf, alt, TP, pl, s, tw, tid, nthreads);
     MVN_SYNC();
@@ -312,17 +317,72 @@ MVN_HD void lds_fft_dif(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, 
 
 // Reverse-order stages: position p holds x[rev[p]] on entry -> natural order out.
 template <int SIGN, int T>
-MVN_HD void lds_fft_dit(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
-                        int tid, int nthreads) {
+MVN_HD void lds_radix_dit(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
+                          int tid, int nthreads) {
   for (int s = pl.nstages - 1; s >= 0; --s) {
     stage_dispatch<SIGN, false, T>(buf, alt, TP, pl, s, tw, tid, nthreads);
     MVN_SYNC();
   }
 }
 
+// Bluestein (chirp-z) transform of the n rows of a tile whose LDS buffer has room for nfft rows:
+//   X[k] = c[k] * sum_j (x[j] c[j]) b[k-j],  c[j] = exp(-i pi j^2/n),  b = conj(c)
+// evaluated as a cyclic convolution of length nfft >= 2n-1 with the radix stages (forward
+// decimation-in-frequency, multiply by the pre-transformed chirp in position order, inverse
+// decimation-in-time).  SIGN = +1 runs the same tables on conjugated data.  Input and output are
+// both in natural order: bluestein axes have identity rev/inv tables.
+template <int SIGN, int T>
+MVN_HD void lds_bluestein(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
+                          int tid, int nthreads) {
+  const int n = pl.n, m = pl.nfft;
+  for (int w = tid; w < m * T; w += nthreads) {
+    const int j = w / T, c = w % T;
+    cfloat v = cmake(0.f, 0.f);
+    if (j < n) {
+      v = buf[j * TP + c];
+      if (SIGN > 0) v = cconj(v);
+      v = cmul(v, pl.chirp[j]);
+    }
+    buf[j * TP + c] = v;
+  }
+  MVN_SYNC();
+  lds_radix_dif<-1, T>(buf, alt, TP, pl, tw, tid, nthreads);
+  for (int w = tid; w < m * T; w += nthreads) {
+    const int p = w / T, c = w % T;
+    buf[p * TP + c] = cmul(buf[p * TP + c], pl.bhat[p]);
+  }
+  MVN_SYNC();
+  lds_radix_dit<+1, T>(buf, alt, TP, pl, tw, tid, nthreads);
+  for (int w = tid; w < n * T; w += nthreads) {
+    const int k = w / T, c = w % T;
+    cfloat v = cmul(buf[k * TP + c], pl.chirp[k]);
+    if (SIGN > 0) v = cconj(v);
+    buf[k * TP + c] = v;
+  }
+  MVN_SYNC();
+}
+
+// The transforms the pass bodies call: radix stages, or the chirp-z route for awkward lengths.
+template <int SIGN, int T>
+MVN_HD void lds_fft_dif(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
+                        int tid, int nthreads) {
+  if (pl.bluestein)
+    lds_bluestein<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+  else
+    lds_radix_dif<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+}
+template <int SIGN, int T>
+MVN_HD void lds_fft_dit(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
+                        int tid, int nthreads) {
+  if (pl.bluestein)
+    lds_bluestein<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+  else
+    lds_radix_dit<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+}
+
 // copy the plan's twiddle table into LDS (stage loops then read it with broadcast ds_reads
 // instead of going through the vector memory pipe)
 MVN_HD const cfloat* lds_stage_twiddles(cfloat* dst, const AxisPlan& pl, int tid, int nthreads) {
-  for (int j = tid; j < pl.n; j += nthreads) dst[j] = pl.tw[j];
+  for (int j = tid; j < pl.nfft; j += nthreads) dst[j] = pl.tw[j];
   return dst;
 }

@@ -24,8 +24,22 @@
 
 namespace mvn {
 
+// next length >= n whose only prime factors are 2, 3, 5, 7
+inline int next_smooth(int n) {
+  for (;; ++n) {
+    int m = n;
+    for (int p : {2, 3, 5, 7})
+      while (m % p == 0) m /= p;
+    if (m == 1) return n;
+  }
+}
+
 struct AxisPlanHost {
   int n = 0;
+  int nfft = 0;            // length of the radix transform: n, or the chirp-z length (bluestein)
+  bool bluestein = false;  // n has a prime factor > kMaxDirectPrime
+  std::vector<cfloat> chirp, bhat;
+  static constexpr int kMaxDirectPrime = 31;  // larger primes go through the chirp-z transform
   std::vector<int> radix;  // DIF order
   std::vector<int> M;
   std::vector<cfloat> tw;
@@ -48,6 +62,28 @@ struct AxisPlanHost {
 
   explicit AxisPlanHost(int n_) : n(n_) {
     if (n < 1) throw std::invalid_argument("mvn: FFT length must be >= 1");
+    nfft = n;
+    {
+      std::vector<int> f = factorize(n);
+      for (int r : f)
+        if (r > kMaxDirectPrime) bluestein = true;
+    }
+    if (bluestein) {
+      nfft = next_smooth(2 * n - 1);
+      build_radix_tables(nfft);
+      // identity position tables: a bluestein axis keeps natural order
+      rev.resize(n);
+      inv.resize(n);
+      for (int j = 0; j < n; ++j) rev[j] = inv[j] = j;
+      build_chirp();
+      return;
+    }
+    build_radix_tables(n);
+  }
+
+  // radix schedule, strides, twiddles and position tables of a length-`len` radix transform
+  void build_radix_tables(int len) {
+    const int n = len;  // shadows the member on purpose: everything below is about `len`
     radix = factorize(n);
     if (radix.empty()) radix.push_back(1);  // n == 1: a single no-op "radix-1" generic stage
     if ((int)radix.size() > MVN_MAX_STAGES)
@@ -100,11 +136,61 @@ struct AxisPlanHost {
     }
   }
 
+  // chirp[j] = exp(-i pi j^2 / n) and the pre-transformed, pre-scaled kernel of the chirp-z
+  // convolution in the position order of the length-nfft forward stages
+  void build_chirp() {
+    const int m = nfft;
+    std::vector<std::pair<double, double>> b((size_t)m, {0.0, 0.0});
+    chirp.resize(n);
+    for (int j = 0; j < n; ++j) {
+      const long jj = ((long)j * j) % (2L * n);  // keeps the angle small
+      const double a = M_PI * (double)jj / (double)n;
+      chirp[j].x = (float)std::cos(a);
+      chirp[j].y = (float)(-std::sin(a));
+      b[j] = {std::cos(a), std::sin(a)};              // conj(chirp)
+      if (j) b[m - j] = b[j];
+    }
+    // plain O(m^2) DFT in double: done once per plan on the host
+    std::vector<std::pair<double, double>> B((size_t)m);
+    std::vector<double> cs((size_t)m), sn((size_t)m);
+    for (int t = 0; t < m; ++t) {
+      cs[t] = std::cos(-2.0 * M_PI * t / m);
+      sn[t] = std::sin(-2.0 * M_PI * t / m);
+    }
+    for (int k = 0; k < m; ++k) {
+      double re = 0, im = 0;
+      for (int j = 0; j < m; ++j) {
+        const int t = (int)(((long)j * k) % m);
+        re += b[j].first * cs[t] - b[j].second * sn[t];
+        im += b[j].first * sn[t] + b[j].second * cs[t];
+      }
+      B[k] = {re / m, im / m};
+    }
+    // position order of the length-m stages: position p holds bin rev_m[p]; the member `rev` was
+    // overwritten with the identity, so recompute the digit reversal here
+    bhat.resize(m);
+    for (int p = 0; p < m; ++p) {
+      int k = 0, w = 1;
+      for (size_t s = 0; s < radix.size(); ++s) {
+        int digit = (p / M[s]) % radix[s];
+        k += digit * w;
+        w *= radix[s];
+      }
+      bhat[p].x = (float)B[k].first;
+      bhat[p].y = (float)B[k].second;
+    }
+  }
+
   // kernel-visible plan; table pointers are filled by whoever owns the (device) copies
   AxisPlan view(const cfloat* tw_p, const int* rev_p, const int* inv_p,
-                const cfloat* tws_p = nullptr) const {
+                const cfloat* tws_p = nullptr, const cfloat* chirp_p = nullptr,
+                const cfloat* bhat_p = nullptr) const {
     AxisPlan a;
     a.n = n;
+    a.nfft = nfft;
+    a.bluestein = bluestein ? 1 : 0;
+    a.chirp = chirp_p;
+    a.bhat = bhat_p;
     a.nstages = (int)radix.size();
     a.generic = generic ? 1 : 0;
     for (int s = 0; s < MVN_MAX_STAGES; ++s) {
@@ -112,7 +198,7 @@ struct AxisPlanHost {
       a.M[s] = s < a.nstages ? M[s] : 1;
       a.Mmul[s] = mvn_fastdiv_mul((unsigned)a.M[s]);
     }
-    a.nmul = mvn_fastdiv_mul((unsigned)n);
+    a.nmul = mvn_fastdiv_mul((unsigned)nfft);
     a.tw = tw_p;
     a.tws = tws_p;
     a.rev = rev_p;

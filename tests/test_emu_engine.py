@@ -123,6 +123,30 @@ def test_backward_vs_pocketfft(emu, shape):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-6
 
 
+# lengths with a prime factor > 31 take the chirp-z (Bluestein) route inside the same passes
+BLUESTEIN_SHAPES = [(37, 41, 74), (4, 271, 6), (271, 4, 8), (6, 5, 542), (67, 8, 134), (3, 3, 37)]
+
+
+@pytest.mark.parametrize("shape", BLUESTEIN_SHAPES)
+def test_bluestein_axes(emu, shape):
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = emu.rfft3(x)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+    back = emu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 5e-5
+
+
+def test_bluestein_deconvolve_vs_oracle(emu):
+    shape = (37, 12, 74)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 3, 7))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    got = emu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, 4)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 def test_ramp_roundtrip_exact(emu):
     # tests/test_plan_store.cu (GPU twin of test_plan_store.cpp:83-142)
     x = np.arange(512, dtype=np.float32).reshape(8, 8, 8)

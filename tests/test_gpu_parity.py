@@ -123,6 +123,29 @@ def test_mixed_radix_fixed_deconvolve_vs_oracle(gpu, orc):
         assert mx <= MAX_REL and rms <= RMS_REL
 
 
+BLUESTEIN_SHAPES = [(37, 41, 74), (4, 271, 6), (271, 4, 8), (6, 5, 542), (67, 8, 134), (3, 3, 37),
+                    (127, 131, 262)]
+
+
+@pytest.mark.parametrize("shape", BLUESTEIN_SHAPES)
+def test_bluestein_axes(gpu, shape):
+    # lengths with a prime factor > 31 take the chirp-z (Bluestein) route inside the same passes
+    x = np.random.default_rng(12).standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = gpu.rfft3(x)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+    back = gpu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 5e-5
+
+
+def test_bluestein_deconvolve_vs_oracle(gpu, orc):
+    shape = (37, 12, 74)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 3, 7))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    mx, rms = rel_err(gpu.gpu_deconvolve(psi0, h), orc.cpu_deconvolve(psi0, h, 4))
+    assert mx <= MAX_REL and rms <= 3 * RMS_REL  # the chirp-z route costs a few extra ulps
+
+
 def test_fixed_and_generic_kernels_agree(gpu, orc, monkeypatch):
     # the same shape through the run-time-radix kernels (MVN_NO_FIXED=1) and the specialised ones
     shape = (64, 64, 128)

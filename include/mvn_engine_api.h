@@ -20,6 +20,10 @@ typedef struct mvn_engine mvn_engine; /* opaque */
 MVN_API const char* mvn_last_error(void);
 MVN_API const char* mvn_backend_name(void);
 
+/* inplace_gpu_deconvolve keeps one resident engine per device between calls (same shape and view
+ * count are re-used without re-allocating; MVN_ENGINE_CACHE=0 disables it).  This frees them. */
+MVN_API int mvn_release_cached_engines(void);
+
 /* ---- plan_store (inc/plan_store.cuh: get()/add/has_key/empty/size/clear) ---------------- */
 MVN_API int mvn_plan_store_add(int device, const int dims[3]);
 MVN_API int mvn_plan_store_has_key(int device, const int dims[3]); /* 1 / 0 */

@@ -3,6 +3,7 @@
 // caller's in/out buffers untouched, print one diagnostic to stderr and never terminate the
 // host process (SURVEY.md 8b "Errors").
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mvn_engine_api.h"
@@ -51,6 +53,40 @@ static std::mutex& device_mutex(int device) {
   auto& m = table[device];
   if (!m) m.reset(new std::mutex());
   return *m;
+}
+
+// One resident engine per device is kept between inplace_gpu_deconvolve calls: Fiji deconvolves
+// block after block of the same shape, and allocating / freeing 4V+2 volumes per call costs more
+// than uploading them.  A call with another shape or view count replaces the
+// cached engine.  MVN_ENGINE_CACHE=0 disables the cache; mvn_release_cached_engines() empties it.
+static std::map<int, std::unique_ptr<Engine>>& engine_cache() {
+  static std::map<int, std::unique_ptr<Engine>>* c = new std::map<int, std::unique_ptr<Engine>>();
+  return *c;
+}
+
+static bool engine_cache_enabled() {
+  const char* e = std::getenv("MVN_ENGINE_CACHE");
+  return !(e && std::strcmp(e, "0") == 0);
+}
+
+// caller holds device_mutex(dev)
+static std::unique_ptr<Engine> take_engine(int dev, const shape_t& ext, int V) {
+  auto& c = engine_cache();
+  auto it = c.find(dev);
+  if (it != c.end()) {
+    std::unique_ptr<Engine> e = std::move(it->second);
+    c.erase(it);
+    if (e && engine_cache_enabled()) {
+      const Layout& L = e->layout();
+      if (L.d0 == ext[0] && L.d1 == ext[1] && L.d2 == ext[2] && e->num_views() == V) return e;
+    }
+    e.reset();  // wrong shape: free its memory before the new engine allocates
+  }
+  return std::unique_ptr<Engine>(new Engine(dev, ext, V));
+}
+
+static void give_back_engine(int dev, std::unique_ptr<Engine> e) {
+  if (engine_cache_enabled()) engine_cache()[dev] = std::move(e);
 }
 
 static int pick_device(int device) {
@@ -195,17 +231,75 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
                   need / 1048576.0, free_b / 1048576.0, need < free_b ? "all on device!" : "does not fit");
     if (need >= (double)free_b)
       throw std::runtime_error("FFT: Unable to run on GPU due to memory constraints");
-    Engine eng(dev, ext, V);
+    std::unique_ptr<Engine> eng_owner = take_engine(dev, ext, V);  // on failure it is simply dropped
+    Engine& eng = *eng_owner;
+    eng.begin_call();
     eng.set_quotient_guard(good_size);
     if (!zero_pad) {
-      for (int v = 0; v < V; ++v) {
-        const view_data& d = input.data_[v];
-        eng.set_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+      static const bool no_pipeline = [] {
+        const char* e = std::getenv("MVN_NO_PIPELINE");
+        return e && *e && std::strcmp(e, "0") != 0;
+      }();
+      if (no_pipeline) {
+        for (int v = 0; v < V; ++v) {
+          const view_data& d = input.data_[v];
+          eng.set_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+        }
+        eng.set_psi(psi);
+        eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
+      } else {
+        // stacks arrive view by view from a second host thread while the first iteration already
+        // runs on the views that are in (the reference's interleaved driver)
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+          if (!trace_on()) return;
+          auto t1 = std::chrono::steady_clock::now();
+          std::printf("[lmvn::trace] %-28s %8.1f ms\n", what,
+                      std::chrono::duration<double, std::milli>(t1 - t0).count());
+          t0 = t1;
+        };
+        eng.reserve_views();
+        lap("allocate view buffers");
+        eng.set_psi(psi);
+        lap("upload psi");
+        std::exception_ptr up_err;
+        std::thread uploader([&] {
+          try {
+            auto u0 = std::chrono::steady_clock::now();
+            for (int v = 0; v < V; ++v) {
+              const view_data& d = input.data_[v];
+              eng.stage_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+            }
+            eng.finish_staging();
+            if (trace_on())
+              std::printf("[lmvn::trace] %-28s %8.1f ms (uploader thread)\n", "stage all views",
+                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count());
+          } catch (...) {
+            up_err = std::current_exception();
+            eng.staging_failed();
+          }
+        });
+        std::exception_ptr main_err;
+        try {
+          eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
+        } catch (...) {
+          main_err = std::current_exception();
+        }
+        lap("enqueue iterations");
+        uploader.join();
+        lap("join uploader");
+        if (up_err) std::rethrow_exception(up_err);
+        if (main_err) std::rethrow_exception(main_err);
+        eng.sync();
+        lap("wait for the device");
+        eng.get_psi(psi);
+        lap("download psi");
+        give_back_engine(dev, std::move(eng_owner));
+        return;
       }
-      eng.set_psi(psi);
-      eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
       eng.sync();
       eng.get_psi(psi);
+      give_back_engine(dev, std::move(eng_owner));
       return;
     }
     // zero_padd: embed on the host (insert_at_offsets, inc/padd_utils.h:160-190), crop on exit
@@ -234,6 +328,7 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
         std::memcpy(psi + ((size_t)z * dims[1] + y) * dims[2],
                     &a[((size_t)(z + off[0]) * ext[1] + (y + off[1])) * ext[2] + off[2]],
                     sizeof(float) * (size_t)dims[2]);
+    give_back_engine(dev, std::move(eng_owner));
   });
 }
 
@@ -422,6 +517,17 @@ void compute_final_values(imageType* _image, imageType* _integral, imageType* _w
 // ---------------------------------------------------------------------------------------------
 // plan_store
 // ---------------------------------------------------------------------------------------------
+int mvn_release_cached_engines(void) {
+  return guarded("mvn_release_cached_engines", [&] {
+    std::vector<int> devs;
+    for (auto& kv : engine_cache()) devs.push_back(kv.first);
+    for (int d : devs) {
+      std::lock_guard<std::mutex> lk(device_mutex(d));
+      engine_cache().erase(d);
+    }
+  });
+}
+
 int mvn_plan_store_add(int device, const int dims[3]) {
   return guarded("mvn_plan_store_add", [&] { PlanStore::get().add(pick_device(device), to_shape(dims)); });
 }
@@ -436,7 +542,10 @@ int mvn_plan_store_has_key(int device, const int dims[3]) {
 int mvn_plan_store_size(void) { return (int)PlanStore::get().size(); }
 int mvn_plan_store_empty(void) { return PlanStore::get().empty() ? 1 : 0; }
 int mvn_plan_store_clear(void) {
-  return guarded("mvn_plan_store_clear", [&] { PlanStore::get().clear(); });
+  return guarded("mvn_plan_store_clear", [&] {
+    mvn_release_cached_engines();  // a cached engine would keep using its old plan
+    PlanStore::get().clear();
+  });
 }
 
 int mvn_plan_describe(int device, const int dims[3], int out[12]) {

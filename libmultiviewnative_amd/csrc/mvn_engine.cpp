@@ -560,16 +560,41 @@ Engine::~Engine() {
   } catch (...) {
   }
   side_.destroy();
+  try {
+    if (upload_stream_) be::stream_sync(upload_stream_);
+  } catch (...) {
+  }
+  for (size_t i = 0; i < stage_scratch_.size(); ++i) be::dfree(stage_scratch_[i]);
+  for (size_t i = 0; i < staged_ev_.size(); ++i) be::event_destroy(staged_ev_[i]);
+  if (upload_stream_) be::stream_destroy(upload_stream_);
   if (stream_) be::stream_destroy(stream_);
 }
 
-void Engine::upload_volume(float* dst, const float* host) {
+void Engine::upload_volume(float* dst, const float* host, be::stream_t s) {
   const Layout& L = plan_->L;
   if (L.RP == L.d2)
-    be::h2d(dst, host, L.logical() * sizeof(float), stream_);
+    be::h2d(dst, host, L.logical() * sizeof(float), s);
   else
     be::h2d_2d(dst, (size_t)L.RP * sizeof(float), host, (size_t)L.d2 * sizeof(float),
-               (size_t)L.d2 * sizeof(float), L.rows, stream_);
+               (size_t)L.d2 * sizeof(float), L.rows, s);
+}
+
+void Engine::alloc_view(ViewSlot& s) {
+  const size_t mb = plan_->main_bytes(), nb = plan_->nyq_bytes();
+  if (s.image) return;
+  s.image = (float*)be::dmalloc(mb);
+  s.weights = (float*)be::dmalloc(mb);
+  s.spec1 = (float*)be::dmalloc(mb);
+  s.spec2 = (float*)be::dmalloc(mb);
+  if (nb) {
+    s.nyq1 = (cfloat*)be::dmalloc(nb);
+    s.nyq2 = (cfloat*)be::dmalloc(nb);
+  }
+  if (plan_->L.RP != plan_->L.d2) {  // odd d2: the row pad must hold zeros
+    be::dzero(s.image, mb, stream_);
+    be::dzero(s.weights, mb, stream_);
+    be::stream_sync(stream_);
+  }
 }
 
 void Engine::set_view(int v, const float* image, const float* weights, const float* kernel1,
@@ -577,21 +602,9 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
   if (v < 0 || v >= (int)views_.size()) throw std::out_of_range("mvn: view index");
   be::set_device(device_);
   ViewSlot& s = views_[(size_t)v];
-  const size_t mb = plan_->main_bytes(), nb = plan_->nyq_bytes();
-  if (!s.image) {
-    s.image = (float*)be::dmalloc(mb);
-    s.weights = (float*)be::dmalloc(mb);
-    s.spec1 = (float*)be::dmalloc(mb);
-    s.spec2 = (float*)be::dmalloc(mb);
-    be::dzero(s.image, mb, stream_);
-    be::dzero(s.weights, mb, stream_);
-    if (nb) {
-      s.nyq1 = (cfloat*)be::dmalloc(nb);
-      s.nyq2 = (cfloat*)be::dmalloc(nb);
-    }
-  }
-  upload_volume(s.image, image);
-  upload_volume(s.weights, weights);
+  alloc_view(s);
+  upload_volume(s.image, image, stream_);
+  upload_volume(s.weights, weights, stream_);
   const float scale = (float)(1.0 / (double)plan_->L.logical());  // inc/cpu_convolve.h:271-274
   const float* ks[2] = {kernel1, kernel2};
   const int* kd[2] = {k1dims, k2dims};
@@ -614,9 +627,74 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
   s.set = true;
 }
 
+// ---- pipelined staging ------------------------------------------------------------------------
+void Engine::reserve_views() {
+  be::set_device(device_);
+  for (size_t v = 0; v < views_.size(); ++v) alloc_view(views_[v]);
+  if (!upload_stream_) upload_stream_ = be::stream_create();
+  staged_ev_.resize(views_.size(), nullptr);
+  for (size_t v = 0; v < views_.size(); ++v)
+    if (!staged_ev_[v]) staged_ev_[v] = be::event_create();
+  staged_.assign(views_.size(), 0);
+  pipelined_ = true;
+}
+
+void Engine::stage_view(int v, const float* image, const float* weights, const float* kernel1,
+                        const int* k1dims, const float* kernel2, const int* k2dims) {
+  be::set_device(device_);  // the HIP device is per host thread
+  ViewSlot& s = views_[(size_t)v];
+  upload_volume(s.image, image, upload_stream_);
+  upload_volume(s.weights, weights, upload_stream_);
+  const float scale = (float)(1.0 / (double)plan_->L.logical());
+  const float* ks[2] = {kernel1, kernel2};
+  const int* kd[2] = {k1dims, k2dims};
+  float* specs[2] = {s.spec1, s.spec2};
+  cfloat* nyqs[2] = {s.nyq1, s.nyq2};
+  for (int i = 0; i < 2; ++i) {
+    const size_t kb = sizeof(float) * (size_t)kd[i][0] * (size_t)kd[i][1] * (size_t)kd[i][2];
+    float* dk = (float*)be::dmalloc(kb);
+    stage_scratch_.push_back(dk);  // freed in finish_staging(), after the stream has drained
+    be::h2d(dk, ks[i], kb, upload_stream_);
+    plan_->psf_spectrum(dk, kd[i], scale, specs[i], nyqs[i], upload_stream_);
+  }
+  be::event_record(staged_ev_[(size_t)v], upload_stream_);
+  s.set = true;
+  {
+    std::lock_guard<std::mutex> lk(stage_mu_);
+    staged_[(size_t)v] = 1;
+  }
+  stage_cv_.notify_all();
+}
+
+void Engine::staging_failed() {
+  {
+    std::lock_guard<std::mutex> lk(stage_mu_);
+    for (size_t v = 0; v < staged_.size(); ++v)
+      if (staged_[v] == 0) staged_[v] = -1;
+  }
+  stage_cv_.notify_all();
+}
+
+void Engine::finish_staging() {
+  be::set_device(device_);
+  if (upload_stream_) be::stream_sync(upload_stream_);
+  for (size_t i = 0; i < stage_scratch_.size(); ++i) be::dfree(stage_scratch_[i]);
+  stage_scratch_.clear();
+}
+
+// main thread: block until the uploader has enqueued view v, then make the compute stream wait
+// for the upload stream's event
+void Engine::wait_staged(int v) {
+  std::unique_lock<std::mutex> lk(stage_mu_);
+  stage_cv_.wait(lk, [&] { return staged_[(size_t)v] != 0; });
+  if (staged_[(size_t)v] < 0) throw std::runtime_error("mvn: staging of view " + std::to_string(v) + " failed");
+  lk.unlock();
+  be::stream_wait_event(stream_, staged_ev_[(size_t)v]);
+}
+
 void Engine::set_psi(const float* host) {
   be::set_device(device_);
-  upload_volume(psi_, host);
+  upload_volume(psi_, host, stream_);
   be::stream_sync(stream_);
 }
 
@@ -694,6 +772,7 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
   const int V = (int)views_.size();
   for (int it = 0; it < iterations; ++it)
     for (int v = 0; v < V; ++v) {
+      if (pipelined_ && it == 0) wait_staged(v);  // the uploader thread may still be busy with v
       const bool last = (it == iterations - 1) && (v == V - 1);
       conv_pair(v, lambda, min_value, MVN_EPI_UPDATE, 0, !last);
     }

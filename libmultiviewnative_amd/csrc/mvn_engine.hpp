@@ -10,6 +10,7 @@
 #pragma once
 
 #include <array>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -201,6 +202,19 @@ class Engine {
   void set_psi(const float* host);
   void get_psi(float* host);
 
+  // Pipelined staging for the blocking ABI call (what the reference's "interleaved" driver was
+  // after, src/gpu_deconvolve_methods.cuh:82-326): a second host thread uploads view after view
+  // on its own stream while the first RL iteration already runs on the views that have arrived.
+  //   reserve_views()            main thread: allocate every view's buffers up front
+  //   stage_view(v, ...)         uploader thread: H2D + PSF spectra of view v on the upload stream
+  //   staging_failed()           uploader thread: wake the main thread up after an error
+  //   iterate(...)               main thread: waits for view v only before its first use
+  void reserve_views();
+  void stage_view(int v, const float* image, const float* weights, const float* kernel1,
+                  const int* k1dims, const float* kernel2, const int* k2dims);
+  void staging_failed();
+  void finish_staging();  // uploader thread, after the last view: drain and free scratch
+
   // `iterations` Gauss-Seidel sweeps over all views (the reference order,
   // src/gpu_deconvolve_methods.cuh:487-535); asynchronous on stream()
   void iterate(int iterations, double lambda, float min_value);
@@ -216,16 +230,32 @@ class Engine {
   size_t volume_floats() const { return plan_->L.real_floats(); }
   // quotient 0 wherever the view is exactly 0 (see EpilogueParams::guard_zero_view)
   void set_quotient_guard(bool on) { quotient_guard_ = on; }
+  // a cached engine starts every ABI call from a clean per-call state
+  void begin_call() {
+    pipelined_ = false;
+    quotient_guard_ = false;
+    work_has_psi_spectrum_ = false;
+  }
   void sync();
 
  private:
   void conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate,
                  bool feed_next);
-  void upload_volume(float* dst, const float* host);
+  void upload_volume(float* dst, const float* host, be::stream_t s);
+  void alloc_view(ViewSlot& s);
+  void wait_staged(int v);
   int device_;
   std::shared_ptr<Plan3D> plan_;
   be::stream_t stream_ = nullptr;
   SideStream side_;
+  // staging pipeline
+  be::stream_t upload_stream_ = nullptr;
+  std::vector<be::event_t> staged_ev_;
+  std::vector<int> staged_;  // per view: 0 pending, 1 enqueued on the upload stream, -1 failed
+  bool pipelined_ = false;
+  std::mutex stage_mu_;
+  std::condition_variable stage_cv_;
+  std::vector<float*> stage_scratch_;
   float* psi_ = nullptr;
   float* work_ = nullptr;
   cfloat* work_nyq_ = nullptr;

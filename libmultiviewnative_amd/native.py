@@ -27,7 +27,7 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_release_cached_engines", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",

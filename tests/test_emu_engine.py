@@ -353,3 +353,15 @@ def test_golden_rl_small(emu, lam):
     psi0, h, seq, _ = rl_small(lam)
     got = emu.gpu_deconvolve(psi0, h)
     assert np.abs(got - seq).max() <= 1e-4 * np.abs(seq).max()
+
+
+def test_deconvolve_staging_error_leaves_psi_untouched(emu, capfd):
+    # the PSF of the second view is larger than the stack: the uploader thread fails while the main
+    # thread already iterates on view 0 -- the call must come back cleanly with psi untouched
+    shape = (8, 8, 8)
+    views, k1, k2, w = synthetic_views(shape, 2, 3, 3)
+    k1[1] = np.ones((9, 3, 3), np.float32)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
+    psi0 = np.full(shape, 2.0, np.float32)
+    assert np.array_equal(emu.gpu_deconvolve(psi0, h), psi0)
+    assert "kernel extent" in capfd.readouterr().err

@@ -205,7 +205,9 @@ def main():
         delta.zero_()
     run(args.warmup)
     if not args.no_profile:
-        eng.profile(True)
+        # events around the launches of every 5th (view, iteration) of the timed region: enough
+        # samples of every kernel, < 1 % perturbation (all launches: 3 %)
+        eng.profile(5)
     fence()
     t0 = time.perf_counter()
     run(args.steps)

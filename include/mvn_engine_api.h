@@ -70,7 +70,9 @@ MVN_API int mvn_engine_sync(mvn_engine* e);
 /* wall time of `iterations` sweeps measured with events on the engine stream */
 MVN_API int mvn_engine_time_iterate(mvn_engine* e, int iterations, double lambda,
                                     float min_value, float* ms);
-/* per-kernel event timing: enable, run, then read totals.  kind indexes mvn_kernel_kind_name */
+/* per-kernel event timing: enable (1 = every launch, n > 1 = the launches of every n-th
+ * (view, iteration) only, which keeps the events' own cost below 1 %), run, then read totals.
+ * kind indexes mvn_kernel_kind_name */
 MVN_API int mvn_engine_profile(mvn_engine* e, int enable);
 MVN_API int mvn_engine_profile_read(mvn_engine* e, int kind, double* total_ms, long* launches);
 MVN_API int mvn_kernel_kind_count(void);

@@ -809,6 +809,7 @@ int mvn_engine_profile(mvn_engine* e, int enable) {
     E.sync();
     E.profiler().reset();
     E.profiler().enabled = enable != 0;
+    E.profiler().sample_every = enable > 1 ? enable : 1;
   });
 }
 

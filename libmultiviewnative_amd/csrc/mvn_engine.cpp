@@ -718,7 +718,9 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
                        bool feed_next) {
   const ViewSlot& s = views_[(size_t)v];
   if (!s.set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
-  Profiler* prof = prof_.enabled ? &prof_ : nullptr;
+  Profiler* prof = nullptr;
+  if (prof_.enabled && (pair_counter_++ % (prof_.sample_every > 0 ? prof_.sample_every : 1)) == 0)
+    prof = &prof_;
   const Plan3D& P = *plan_;
   cfloat* W = (cfloat*)work_;
   static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;  // A/B knob for experiments

@@ -42,6 +42,7 @@ const char* kernel_kind_name(int k);
 class Profiler {
  public:
   bool enabled = false;
+  int sample_every = 1;  // time every n-th (view, iteration) only: keeps the events' own cost low
   void begin(int kind, be::stream_t s);
   void end(be::stream_t s);
   // waits for the recorded events and folds them into the totals
@@ -265,7 +266,8 @@ class Engine {
   float* psi_spec_ = nullptr;
   cfloat* psi_spec_nyq_ = nullptr;
   bool work_has_psi_spectrum_ = false;
-  bool quotient_guard_ = false;  // work_ holds the last-axis transform of the current psi
+  bool quotient_guard_ = false;
+  long pair_counter_ = 0;  // work_ holds the last-axis transform of the current psi
   std::vector<ViewSlot> views_;
   Profiler prof_;
 };

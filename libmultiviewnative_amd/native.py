@@ -262,7 +262,8 @@ class EngineHandle:
         self.b.check(self.b.l.mvn_engine_sync(self.h))
 
     def profile(self, enable):
-        self.b.check(self.b.l.mvn_engine_profile(self.h, 1 if enable else 0))
+        """enable: False/0 off, True/1 every launch, n > 1 the launches of every n-th (view, iteration)."""
+        self.b.check(self.b.l.mvn_engine_profile(self.h, int(enable)))
 
     def profile_read(self):
         out = {}

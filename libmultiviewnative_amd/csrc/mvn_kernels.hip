@@ -82,8 +82,17 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams
   fx_rows_c2r_body<H, EPI>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
+// The divide form needs 93 VGPRs unconstrained - just above the 84 that let three 512-thread
+// workgroups share a CU; asking for 6 waves per SIMD makes the allocator fit.
+#ifndef MVN_ROWS_DIV_WAVES
+#define MVN_ROWS_DIV_WAVES 1
+#endif
+constexpr int fx_rows_fused_waves(int nt, int epi) {
+  return (epi == MVN_EPI_DIVIDE && nt == 512) ? MVN_ROWS_DIV_WAVES : 1;
+}
 template <int H, int EPI>
-__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p) {
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT, fx_rows_fused_waves(FxRowsCfg<H>::NT, EPI))
+    kx_rows_c2r_r2c(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;

@@ -94,6 +94,21 @@ MVN_API void compute_quotient(imageType* _input, imageType* _output, size_t _siz
 MVN_API void compute_final_values(imageType* _image, imageType* _integral, imageType* _weight,
                                   size_t _size, float _minValue, double _lambda, int _device);
 
+/* inc/multiviewnative.h:94-96 (impl. src/multiviewnative.cu:395-506): ONE Richardson-Lucy step
+ * on a single host stack, the legacy demo path: psi_0 = view = _input, kernel1 = _kernel,
+ * kernel2 = 0.1 in every tap (extents of _kernel), weights = 1, minValue = 1e-4, lambda = 0;
+ * both convolutions cyclic on _input_dims.  _output receives the updated estimate. */
+MVN_API void iterate_fft_plain(imageType* _input, imageType* _kernel, imageType* _output,
+                               int* _input_dims, int* _kernel_dims, int _device);
+
+/* inc/multiviewnative.h:98-102 (impl. src/multiviewnative.cu:508-600): as iterate_fft_plain, with
+ * the legacy Tikhonov update of inc/cuda_kernels.cuh:162-193: t = image * integral;
+ * t = t > 0 ? float((sqrt(1 + 2 * float(lambda) * t) - 1) / float(lambda)) : minValue;
+ * out = w * (max(minValue, t) - t) + t (w = 1).  _size is unused (as in the reference). */
+MVN_API void iterate_fft_tikhonov(imageType* _input, imageType* _kernel, imageType* _output,
+                                  int* _input_dims, int* _kernel_dims, size_t _size,
+                                  float _minValue, double _lambda, int _device);
+
 /* inc/multiviewnative.h:104-109 (impl. inc/cuda_helpers.cuh:70-136).  The "CUDA" names are
  * kept for ABI compatibility; they report HIP devices.  "Compute capability" is the gfx
  * target split as major = gfx / 10 (e.g. 95), minor = gfx % 10 for gfx950. */

@@ -396,6 +396,55 @@ void convolution3DfftCUDAInPlace(imageType* im, int* imDim, imageType* kernel, i
   guarded("convolution3DfftCUDAInPlace", [&] { convolve_host(im, imDim, kernel, kernelDim, devCUDA); });
 }
 
+// device-pointer convolution on an already selected device; the caller holds the device mutex
+static void core_convolve_on_device(float* d_im, const int* imDim, const float* d_kernel,
+                                    const int* kernelDim, int dev) {
+  std::shared_ptr<Plan3D> plan = PlanStore::get().add(dev, to_shape(imDim));
+  const Layout& L = plan->L;
+  be::stream_t s = be::stream_create();
+  float *vol = nullptr, *spec = nullptr;
+  cfloat *nyq = nullptr, *snyq = nullptr;
+  auto cleanup = [&] {
+    if (vol != d_im) be::dfree(vol);
+    be::dfree(spec);
+    be::dfree(nyq);
+    be::dfree(snyq);
+    be::stream_destroy(s);
+  };
+  try {
+    spec = (float*)be::dmalloc(plan->main_bytes());
+    if (plan->nyq_bytes()) {
+      nyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
+      snyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
+    }
+    if (L.RP == L.d2) {
+      vol = d_im;  // even d2: the caller's dense volume already is the engine layout
+    } else {
+      vol = (float*)be::dmalloc(plan->main_bytes());
+      be::dzero(vol, plan->main_bytes(), s);
+      be::d2d_2d(vol, (size_t)L.RP * 4, d_im, (size_t)L.d2 * 4, (size_t)L.d2 * 4, L.rows, s);
+    }
+    const float scale = (float)(1.0 / (double)L.logical());
+    plan->psf_spectrum(d_kernel, kernelDim, scale, spec, snyq, s);
+    EpilogueParams e;
+    std::memset(&e, 0, sizeof(e));
+    e.mode = MVN_EPI_STORE;
+    e.scale = 1.f;
+    plan->convolve(vol, (cfloat*)vol, nyq, (const cfloat*)spec, snyq, vol, e, s);
+    if (vol != d_im)
+      be::d2d_2d(d_im, (size_t)L.d2 * 4, vol, (size_t)L.RP * 4, (size_t)L.d2 * 4, L.rows, s);
+    be::stream_sync(s);
+  } catch (...) {
+    try {
+      be::stream_sync(s);
+    } catch (...) {
+    }
+    cleanup();
+    throw;
+  }
+  cleanup();
+}
+
 void convolution3DfftCUDAInPlace_core(imageType* d_im, int* imDim, imageType* d_kernel,
                                       int* kernelDim, int devCUDA) {
   guarded("convolution3DfftCUDAInPlace_core", [&] {
@@ -403,51 +452,81 @@ void convolution3DfftCUDAInPlace_core(imageType* d_im, int* imDim, imageType* d_
     const int dev = pick_device(devCUDA);
     std::lock_guard<std::mutex> lk(device_mutex(dev));
     be::set_device(dev);
-    std::shared_ptr<Plan3D> plan = PlanStore::get().add(dev, to_shape(imDim));
-    const Layout& L = plan->L;
-    be::stream_t s = be::stream_create();
-    float *vol = nullptr, *spec = nullptr;
-    cfloat *nyq = nullptr, *snyq = nullptr;
+    core_convolve_on_device(d_im, imDim, d_kernel, kernelDim, dev);
+  });
+}
+
+// One Richardson-Lucy step on a single stack, the legacy demo entry points of
+// src/multiviewnative.cu:395-506 (plain) and :508-600 (tikhonov): psi_0 = view = _input,
+// kernel1 = _kernel, kernel2 = 0.1 everywhere (same extents), weights = 1; both convolutions are
+// cyclic on _input_dims (they go through convolution3DfftCUDAInPlace_core there as here).
+static void iterate_fft_legacy(const char* what, const float* input, const float* kernel,
+                               float* output, const int* input_dims, const int* kernel_dims,
+                               bool tikhonov, float min_value, double lambda, int device) {
+  guarded(what, [&] {
+    if (!input || !kernel || !output || !input_dims || !kernel_dims)
+      throw std::invalid_argument("null argument");
+    const size_t n = (size_t)input_dims[0] * input_dims[1] * input_dims[2];
+    const size_t nk = (size_t)kernel_dims[0] * kernel_dims[1] * kernel_dims[2];
+    if (n == 0 || nk == 0) throw std::invalid_argument("empty stack or kernel");
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    be::set_device(dev);
+    float *d_image = nullptr, *d_initial = nullptr, *d_weights = nullptr, *d_kernel = nullptr;
     auto cleanup = [&] {
-      if (vol != d_im) be::dfree(vol);
-      be::dfree(spec);
-      be::dfree(nyq);
-      be::dfree(snyq);
-      be::stream_destroy(s);
+      be::dfree(d_image);
+      be::dfree(d_initial);
+      be::dfree(d_weights);
+      be::dfree(d_kernel);
     };
     try {
-      spec = (float*)be::dmalloc(plan->main_bytes());
-      if (plan->nyq_bytes()) {
-        nyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
-        snyq = (cfloat*)be::dmalloc(plan->nyq_bytes());
-      }
-      if (L.RP == L.d2) {
-        vol = d_im;  // even d2: the caller's dense volume already is the engine layout
-      } else {
-        vol = (float*)be::dmalloc(plan->main_bytes());
-        be::dzero(vol, plan->main_bytes(), s);
-        be::d2d_2d(vol, (size_t)L.RP * 4, d_im, (size_t)L.d2 * 4, (size_t)L.d2 * 4, L.rows, s);
-      }
-      const float scale = (float)(1.0 / (double)L.logical());
-      plan->psf_spectrum(d_kernel, kernelDim, scale, spec, snyq, s);
-      EpilogueParams e;
-      std::memset(&e, 0, sizeof(e));
-      e.mode = MVN_EPI_STORE;
-      e.scale = 1.f;
-      plan->convolve(vol, (cfloat*)vol, nyq, (const cfloat*)spec, snyq, vol, e, s);
-      if (vol != d_im)
-        be::d2d_2d(d_im, (size_t)L.d2 * 4, vol, (size_t)L.RP * 4, (size_t)L.d2 * 4, L.rows, s);
-      be::stream_sync(s);
+      d_image = (float*)be::dmalloc(n * 4);
+      d_initial = (float*)be::dmalloc(n * 4);
+      d_weights = (float*)be::dmalloc(n * 4);
+      d_kernel = (float*)be::dmalloc(nk * 4);
+      std::vector<float> ones(n, 1.f), tenth(nk, .1f);
+      be::h2d(d_weights, ones.data(), n * 4, nullptr);
+      be::h2d(d_initial, input, n * 4, nullptr);
+      be::h2d(d_image, input, n * 4, nullptr);
+      be::h2d(d_kernel, kernel, nk * 4, nullptr);
+      be::stream_sync(nullptr);
+      int idims[3] = {input_dims[0], input_dims[1], input_dims[2]};
+      int kdims[3] = {kernel_dims[0], kernel_dims[1], kernel_dims[2]};
+      core_convolve_on_device(d_image, idims, d_kernel, kdims, dev);  // psi (*) kernel1
+      be::launch_divide(d_initial, d_image, n, nullptr);              // view / blurred
+      be::h2d(d_kernel, tenth.data(), nk * 4, nullptr);
+      be::stream_sync(nullptr);
+      core_convolve_on_device(d_image, idims, d_kernel, kdims, dev);  // (*) kernel2 -> integral
+      if (tikhonov)
+        be::launch_update_legacy_tikhonov(d_initial, d_image, d_weights, n, (float)lambda,
+                                          min_value, nullptr);
+      else
+        be::launch_update(d_initial, d_image, d_weights, n, 0., min_value, nullptr);
+      std::vector<float> tmp(n);
+      be::d2h(tmp.data(), d_initial, n * 4, nullptr);
+      be::stream_sync(nullptr);
+      std::memcpy(output, tmp.data(), n * 4);
     } catch (...) {
-      try {
-        be::stream_sync(s);
-      } catch (...) {
-      }
       cleanup();
       throw;
     }
     cleanup();
   });
+}
+
+void iterate_fft_plain(imageType* _input, imageType* _kernel, imageType* _output, int* _input_dims,
+                       int* _kernel_dims, int _device) {
+  // the reference hard-codes minValue = .0001f here (src/multiviewnative.cu:485-486)
+  iterate_fft_legacy("iterate_fft_plain", _input, _kernel, _output, _input_dims, _kernel_dims,
+                     false, .0001f, 0., _device);
+}
+
+void iterate_fft_tikhonov(imageType* _input, imageType* _kernel, imageType* _output,
+                          int* _input_dims, int* _kernel_dims, size_t _size, float _minValue,
+                          double _lambda, int _device) {
+  (void)_size;  // unused by the reference too (the extent comes from _input_dims)
+  iterate_fft_legacy("iterate_fft_tikhonov", _input, _kernel, _output, _input_dims, _kernel_dims,
+                     true, _minValue, _lambda, _device);
 }
 
 void compute_quotient(imageType* _input, imageType* _output, size_t _size, int _device) {

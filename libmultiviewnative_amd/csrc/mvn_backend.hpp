@@ -77,6 +77,9 @@ void launch_divide(const float* view, float* inout, size_t n, stream_t s);
 void launch_update(float* psi, const float* integral, const float* weights, size_t n,
                    double lambda, float min_value, stream_t s);
 // psi += delta  (applies the all-reduced correction in simultaneous mode)
+// legacy iterate_fft_tikhonov final step (inc/cuda_kernels.cuh:162-193)
+void launch_update_legacy_tikhonov(float* image, const float* integral, const float* weights,
+                                   size_t n, float lambda_f, float min_value, stream_t s);
 void launch_axpy1(float* psi, const float* delta, size_t n, stream_t s);
 
 }  // namespace be

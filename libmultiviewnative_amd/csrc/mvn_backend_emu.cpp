@@ -275,6 +275,12 @@ void launch_update(float* psi, const float* integral, const float* weights, size
   }
 }
 
+void launch_update_legacy_tikhonov(float* image, const float* integral, const float* weights,
+                                   size_t n, float lambda_f, float min_value, stream_t) {
+  for (size_t i = 0; i < n; ++i)
+    image[i] = mvn_legacy_tikhonov_value(image[i], integral[i], weights[i], lambda_f, min_value);
+}
+
 void launch_axpy1(float* psi, const float* delta, size_t n, stream_t) {
   for (size_t i = 0; i < n; ++i) psi[i] += delta[i];
 }

@@ -11,7 +11,8 @@
 //                             (multiply_scaled, inc/cuda_kernels.cuh:213-242) and inverse dim0
 //   k_scatter_psf             device-side wrapped insert (fftShiftKernel,
 //                             src/multiviewnative.cu:154-192)
-//   k_divide / k_update / k_axpy1   stand-alone pointwise ops for the legacy entry points
+//   k_divide / k_update / k_update_legacy_tikhonov / k_axpy1   stand-alone pointwise ops for the
+//                                   legacy entry points
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -131,6 +132,15 @@ __global__ void k_update(float* __restrict__ psi, const float* __restrict__ inte
     const float next = mvn_next_value(last, integral[i], lambda, lambda_inv, min_value);
     psi[i] = weights[i] * (next - last) + last;
   }
+}
+
+__global__ void k_update_legacy_tikhonov(float* __restrict__ image,
+                                        const float* __restrict__ integral,
+                                        const float* __restrict__ weights, size_t n,
+                                        float lambda_f, float min_value) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    image[i] = mvn_legacy_tikhonov_value(image[i], integral[i], weights[i], lambda_f, min_value);
 }
 
 __global__ void k_axpy1(float* __restrict__ psi, const float* __restrict__ delta, size_t n) {
@@ -437,6 +447,13 @@ void launch_update(float* psi, const float* integral, const float* weights, size
   const float linv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
   hipLaunchKernelGGL(k_update, dim3(flat_grid(n, 256)), dim3(256), 0, hs(s), psi, integral,
                      weights, n, lambda, linv, min_value);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_update_legacy_tikhonov(float* image, const float* integral, const float* weights,
+                                   size_t n, float lambda_f, float min_value, stream_t s) {
+  hipLaunchKernelGGL(k_update_legacy_tikhonov, dim3(flat_grid(n, 256)), dim3(256), 0, hs(s), image,
+                     integral, weights, n, lambda_f, min_value);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -87,6 +87,22 @@ MVN_HD float mvn_next_value(float last, float integral, double lambda, float lam
   return next;
 }
 
+// Legacy single-step update of iterate_fft_tikhonov (inc/cuda_kernels.cuh:162-193): lambda arrives
+// as float, the regularised value is formed in double and divided (not multiplied by a
+// reciprocal), there is no NaN/Inf test beyond the comparisons, and the weight blends against the
+// NEW value: w * (max(min, t) - t) + t.
+MVN_HD float mvn_legacy_tikhonov_value(float image, float integral, float weight, float lambda_f,
+                                       float min_value) {
+  MVN_FP_EXACT
+  float t = image * integral;
+  if (t > 0.f)
+    t = (float)((sqrt(1.0 + 2.0 * (double)lambda_f * (double)t) - 1.) / (double)lambda_f);
+  else
+    t = min_value;
+  float nv = (min_value > t) ? min_value : t;
+  return weight * (nv - t) + t;
+}
+
 MVN_HD void mvn_epilogue(const EpilogueParams& e, float* out, long i, float x) {
   MVN_FP_EXACT
   x *= e.scale;

@@ -22,6 +22,7 @@ EMU_SO = os.path.join(LIB_DIR, "libmvn_emu.so")
 REFERENCE_ABI_SYMBOLS = [
     "inplace_gpu_deconvolve", "inplace_gpu_convolution", "convolution3DfftCUDAInPlace",
     "convolution3DfftCUDAInPlace_core", "compute_quotient", "compute_final_values",
+    "iterate_fft_plain", "iterate_fft_tikhonov",
     "selectDeviceWithHighestComputeCapability", "getCUDAcomputeCapabilityMinorVersion",
     "getCUDAcomputeCapabilityMajorVersion", "getNumDevicesCUDA", "getNameDeviceCUDA",
     "getMemDeviceCUDA",
@@ -72,6 +73,11 @@ class Binding:
         l.compute_final_values.argtypes = [c_float_p, c_float_p, c_float_p, C.c_size_t, C.c_float,
                                            C.c_double, C.c_int]
         l.compute_final_values.restype = None
+        l.iterate_fft_plain.argtypes = [c_float_p, c_float_p, c_float_p, c_int_p, c_int_p, C.c_int]
+        l.iterate_fft_plain.restype = None
+        l.iterate_fft_tikhonov.argtypes = [c_float_p, c_float_p, c_float_p, c_int_p, c_int_p,
+                                           C.c_size_t, C.c_float, C.c_double, C.c_int]
+        l.iterate_fft_tikhonov.restype = None
         l.getNameDeviceCUDA.argtypes = [C.c_int, C.c_char_p]
         l.getNameDeviceCUDA.restype = None
         l.getMemDeviceCUDA.argtypes = [C.c_int]
@@ -143,6 +149,21 @@ class Binding:
         self.l.compute_final_values(fptr(psi), fptr(integral), fptr(weight), psi.size, min_value,
                                     lambda_, device)
         return psi
+
+    def iterate_fft(self, image, kernel, min_value=1e-4, lambda_=None, device=0):
+        """iterate_fft_plain (lambda_ None; the reference fixes minValue = 1e-4 there) or
+        iterate_fft_tikhonov: one legacy RL step on a single stack."""
+        im = np.ascontiguousarray(image, dtype=np.float32)
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        out = np.full_like(im, np.nan)
+        idims = np.array(im.shape, np.int32)
+        kdims = np.array(k.shape, np.int32)
+        if lambda_ is None:
+            self.l.iterate_fft_plain(fptr(im), fptr(k), fptr(out), iptr(idims), iptr(kdims), device)
+        else:
+            self.l.iterate_fft_tikhonov(fptr(im), fptr(k), fptr(out), iptr(idims), iptr(kdims),
+                                        im.size, min_value, lambda_, device)
+        return out
 
     # ---- transforms ------------------------------------------------------------------------
     def rfft3(self, x, device=0):

@@ -40,6 +40,9 @@ def _setup(l):
     l.oracle_final_values.argtypes = [c_float_p, c_float_p, c_float_p, C.c_size_t, C.c_float]
     l.oracle_regularized_final_values.argtypes = [c_float_p, c_float_p, c_float_p, C.c_size_t,
                                                   C.c_double, C.c_float]
+    l.oracle_legacy_tikhonov_final_values.argtypes = [c_float_p, c_float_p, c_float_p, C.c_size_t,
+                                                      C.c_float, C.c_float]
+    l.oracle_legacy_tikhonov_final_values.restype = None
     l.oracle_update_delta.argtypes = [c_float_p, c_float_p, c_float_p, c_float_p, C.c_int,
                                       C.c_size_t, C.c_double, C.c_float]
     l.inplace_cpu_convolution.argtypes = [c_float_p, c_int_p, c_float_p, c_int_p, C.c_int]
@@ -132,6 +135,30 @@ def final_values(psi, integral, weight, min_value, lambda_=0.0):
     else:
         lib().oracle_final_values(_fp(psi), _fp(integral), _fp(weight), psi.size, min_value)
     return psi
+
+
+def legacy_tikhonov_final_values(image, integral, weight, min_value, lambda_):
+    image = np.ascontiguousarray(image, dtype=np.float32).copy()
+    integral = np.ascontiguousarray(integral, dtype=np.float32)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    lib().oracle_legacy_tikhonov_final_values(_fp(image), _fp(integral), _fp(weight), image.size,
+                                              min_value, lambda_)
+    return image
+
+
+def iterate_fft(image, kernel, min_value=1e-4, lambda_=None, nthreads=1):
+    """The legacy one-step entry points restated from src/multiviewnative.cu:395-506 (plain,
+    lambda_ None) and :508-600 (tikhonov): psi_0 = view = image, kernel2 = 0.1 in every tap,
+    weights = 1, both convolutions cyclic."""
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    kernel = np.ascontiguousarray(kernel, dtype=np.float32)
+    blurred = cpu_convolution(image, kernel, nthreads)
+    quotient = compute_quotient(image, blurred)
+    integral = cpu_convolution(quotient, np.full_like(kernel, .1), nthreads)
+    ones = np.ones_like(image)
+    if lambda_ is None:
+        return final_values(image, integral, ones, min_value, 0.0)
+    return legacy_tikhonov_final_values(image, integral, ones, min_value, lambda_)
 
 
 def cpu_deconvolve(psi, holder, nthreads=1):

@@ -448,6 +448,25 @@ void oracle_regularized_final_values(float* psi, const float* integral, const fl
   }
 }
 
+/* inc/cuda_kernels.cuh:162-193 (device_finalValues_tikhonov, the update of the legacy
+ * iterate_fft_tikhonov entry, src/multiviewnative.cu:588-590): lambda is a float there, the
+ * regularised value is divided by lambda in double, and the weight blends against the new value. */
+void oracle_legacy_tikhonov_final_values(float* image, const float* integral, const float* weight,
+                                         size_t size, float minValue, float lambda) {
+  for (size_t i = 0; i < size; ++i) {
+    float temp_image = image[i];
+    temp_image *= integral[i];                                                   /* :180-181 */
+    float temp_weight = weight[i];
+    if (temp_image > 0.f)
+      temp_image = (float)((sqrt(1.0 + 2.0 * lambda * temp_image) - 1.) / lambda); /* :185 */
+    else
+      temp_image = minValue;
+    float new_value = (minValue > temp_image) ? minValue : temp_image;           /* cmax, :189 */
+    new_value = temp_weight * (new_value - temp_image) + temp_image;             /* :190 */
+    image[i] = new_value;
+  }
+}
+
 /* the per-view additive correction w*(next-last) of the formulas above, WITHOUT applying it:
  * building block of the simultaneous (Jacobi) multi-GPU mode. */
 void oracle_update_delta(const float* psi, const float* integral, const float* weight,

@@ -365,3 +365,33 @@ def test_deconvolve_staging_error_leaves_psi_untouched(emu, capfd):
     psi0 = np.full(shape, 2.0, np.float32)
     assert np.array_equal(emu.gpu_deconvolve(psi0, h), psi0)
     assert "kernel extent" in capfd.readouterr().err
+
+
+def _legacy_case(seed, shape, kshape):
+    rng = np.random.default_rng(seed)
+    image = rng.uniform(1, 20, shape).astype(np.float32)
+    kernel = rng.uniform(0, 1, kshape).astype(np.float32)
+    kernel /= kernel.sum()
+    return image, kernel
+
+
+@pytest.mark.parametrize("shape,kshape", [((16, 16, 16), (3, 3, 3)), ((12, 10, 9), (5, 3, 3))])
+def test_iterate_fft_legacy_steps(emu, shape, kshape):
+    # src/multiviewnative.cu:395-600: one RL step with kernel2 = 0.1, weights = 1
+    image, kernel = _legacy_case(3, shape, kshape)
+    got = emu.iterate_fft(image, kernel)
+    ref = orc.iterate_fft(image, kernel)
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    for lam in (0.006, 0.5):
+        got = emu.iterate_fft(image, kernel, 1e-3, lam)
+        ref = orc.iterate_fft(image, kernel, 1e-3, lam)
+        assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    # an integral of 0.1 * sum(quotient) is far above minValue: the legacy blend returns t itself
+    integral = orc.cpu_convolution(orc.compute_quotient(image, orc.cpu_convolution(image, kernel)),
+                                   np.full_like(kernel, .1))
+    lf = np.float32(0.006)
+    t = ((np.sqrt(1.0 + 2.0 * np.float64(lf) * (image * integral).astype(np.float64)) - 1.0)
+         / np.float64(lf)).astype(np.float32)
+    got = emu.iterate_fft(image, kernel, 1e-3, 0.006)
+    assert np.abs(got - t).max() <= 2e-6 * np.abs(t).max()

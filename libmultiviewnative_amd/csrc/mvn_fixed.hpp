@@ -215,9 +215,6 @@ MVN_HD void fx_copy_table(cfloat* dst, const cfloat* src, int count, int tid) {
   for (int i = tid; i < count; i += NT) dst[i] = src[i];
 }
 
-// ---------------------------------------------------------------------------------------------
-// strided-axis pass, full tiles of T neighbouring bins (cstride == 1, ncols % T == 0)
-// ---------------------------------------------------------------------------------------------
 // largest multiple of 64 that is <= min(cap, full) and divides a, b and c (0 if none)
 constexpr int fx_pick_nt(int cap, int full, int a, int b, int c) {
   for (int nt = cap; nt >= 64; nt -= 64)
@@ -225,6 +222,10 @@ constexpr int fx_pick_nt(int cap, int full, int a, int b, int c) {
   return 0;
 }
 
+#ifdef MVN_FX_STRIDED_V1
+// ---------------------------------------------------------------------------------------------
+// strided-axis pass, full tiles of T neighbouring bins (cstride == 1, ncols % T == 0)
+// ---------------------------------------------------------------------------------------------
 template <int N>
 struct FxStridedCfg {
   // 128-byte row segments wherever the tile fits the LDS at all (two workgroups per CU up to
@@ -326,6 +327,294 @@ MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx
   }
   MVN_PHASE(ctx, (fx_st_store<N, MODE>(P, base, buf, tid)));
 }
+
+#else
+// ---------------------------------------------------------------------------------------------
+// strided-axis pass, full tiles of T neighbouring bins (cstride == 1, ncols % T == 0).
+//
+// A thread owns one 16-byte chunk (two neighbouring bins) of a tile row, so every butterfly is
+// done on two columns at once with 16-byte LDS accesses and one shared twiddle row.  The outer
+// stages never touch the LDS:
+//   stage 0 (radix 8, input stride M0 = N/8) sits right behind the global loads of a forward
+//   transform / right before the global stores of an inverse one (thread <-> rows j2 + k M0),
+//   the last stage (M = 1) sits right before the stores of a forward transform / behind the loads
+//   of an inverse one (thread <-> rows b R + k); in the fused FWD*PSF*INV pass the last forward
+//   stage, the multiplication by the PSF spectrum and the first inverse stage are one register
+//   sequence.
+// That leaves ns-1 LDS round trips per transform (2 for N = 512; the fused pass 4 instead of 8).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct FxStridedCfg {
+  // 128-byte row segments wherever the tile fits the LDS at all (two workgroups per CU up to
+  // N = 576, one beyond; measured: 64-byte segments cost 15-30 % of the pass at N = 640..1024)
+  static constexpr int T = N <= 1024 ? 16 : 8;
+  static constexpr int TP = T;
+  static constexpr int CH = T / 2;    // 16-byte chunks per tile row
+  static constexpr int TPQ = TP / 2;  // row pitch in 16-byte units
+  static constexpr int NS = fx_nstages(N);
+  static constexpr int R0 = fx_radix(N, 0), M0 = fx_M(N, 0);
+  static constexpr int RL = fx_radix(N, NS - 1);  // radix of the last stage (M = 1)
+  static constexpr int NT = M0 * CH;              // one stage-0 butterfly (on two columns) per thread
+  static constexpr int NWL = (N / RL) * CH;       // work items of the last stage
+  static constexpr int ITL = (NWL + NT - 1) / NT;
+  static constexpr int lds_cfloats = N * TP + fx_twsize(N);
+  static_assert(fx_smooth(N) && N >= 64 && N <= 2048 && N % 64 == 0, "unsupported fixed length");
+  static_assert(R0 == 8 && NS >= 2 && M0 > 1 && fx_M(N, NS - 1) == 1, "unexpected radix plan");
+  static_assert(NT % 64 == 0 && NT <= 1024, "workgroup size");
+  static_assert(sizeof(cfloat) * lds_cfloats <= 160 * 1024, "tile does not fit the LDS");
+};
+
+template <int N>
+struct FxStridedRegs {
+  qfloat g[FxStridedCfg<N>::ITL * FxStridedCfg<N>::RL];  // PSF-spectrum operands (fused pass)
+};
+
+// one radix-R butterfly on both complex halves of R 16-byte registers
+template <int R, int SIGN>
+MVN_HD void fx_dft_q(qfloat* a) {
+  cfloat lo[R], hi[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    lo[k] = cmake(a[k].x, a[k].y);
+    hi[k] = cmake(a[k].z, a[k].w);
+  }
+  dftR<R, SIGN>(lo);
+  dftR<R, SIGN>(hi);
+#pragma unroll
+  for (int k = 0; k < R; ++k) a[k] = qmake(lo[k].x, lo[k].y, hi[k].x, hi[k].y);
+}
+
+MVN_HD qfloat fx_qmul_c(qfloat a, cfloat w) {  // both halves times one complex factor
+  return qmake(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x, a.z * w.x - a.w * w.y,
+               a.z * w.y + a.w * w.x);
+}
+
+MVN_HD qfloat fx_qmul_q(qfloat a, qfloat g) {  // half-wise complex product
+  return qmake(a.x * g.x - a.y * g.y, a.x * g.y + a.y * g.x, a.z * g.z - a.w * g.w,
+               a.z * g.w + a.w * g.z);
+}
+
+template <int R>
+MVN_HD void fx_tw_row(const cfloat* row, cfloat* tw) {  // fx_rs(R) entries, 16-byte aligned
+  const qfloat* t4 = reinterpret_cast<const qfloat*>(row);
+#pragma unroll
+  for (int k = 0; k < fx_rs(R) / 2; ++k) {
+    const qfloat t = t4[k];
+    tw[2 * k] = cmake(t.x, t.y);
+    tw[2 * k + 1] = cmake(t.z, t.w);
+  }
+}
+
+// an inner stage (1 <= S <= ns-2, so M > 1) through the LDS
+template <int N, int NT, int S, int SIGN, bool DIF>
+MVN_HD void fx_stage_q(cfloat* bufc, const cfloat* tws, int tid) {
+  typedef FxStridedCfg<N> C;
+  constexpr int R = fx_radix(N, S), M = fx_M(N, S), CH = C::CH, TPQ = C::TPQ;
+  constexpr int nwork = (N / R) * CH;
+  constexpr int iters = (nwork + NT - 1) / NT;
+  qfloat* buf = reinterpret_cast<qfloat*>(bufc);
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
+    const int w = tid + it * NT;
+    if (nwork % NT != 0 && w >= nwork) break;
+    const int b = w / CH, q = w % CH;
+    const int blk = b / M, j2 = b % M;
+    qfloat* p = buf + (blk * R * M + j2) * TPQ + q;
+    qfloat a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = p[j * M * TPQ];
+    cfloat tw[fx_rs(R)];
+    fx_tw_row<R>(tws + fx_twoff(N, S) + j2 * fx_rs(R), tw);
+    if (!DIF) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+    }
+    fx_dft_q<R, SIGN>(a);
+    if (DIF) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) p[j * M * TPQ] = a[j];
+  }
+}
+
+// inner stages S = FROM, FROM +- 1, ..., TO as phases (DIF upwards, DIT downwards)
+template <int N, int NT, int SIGN, bool DIF, int S, int TO, typename Ctx>
+struct FxStagesQ {
+  static MVN_HD void run(cfloat* buf, const cfloat* tws, Ctx& ctx) {
+    constexpr int NT_ = NT;
+    (void)NT_;
+    if constexpr (DIF ? (S <= TO) : (S >= TO)) {
+      MVN_PHASE(ctx, (fx_stage_q<N, NT, S, SIGN, DIF>(buf, tws, tid)));
+      FxStagesQ<N, NT, SIGN, DIF, DIF ? S + 1 : S - 1, TO, Ctx>::run(buf, tws, ctx);
+    }
+  }
+};
+
+// phase functions (plain functions so that loop pragmas are honoured; MVN_PHASE only calls them)
+
+// forward entry: global loads, stage 0 in registers (twiddles straight from the global table,
+// which the same phase copies to the LDS for the later stages), PSF operands prefetched
+template <int N, int MODE>
+MVN_HD void fx_st_load_first(const StridedParams& P, long base, cfloat* buf, cfloat* tws,
+                             FxStridedRegs<N>& r, int tid) {
+  typedef FxStridedCfg<N> C;
+  constexpr int M0 = C::M0, CH = C::CH;
+  const int q = tid % CH, j2 = tid / CH;
+  const cfloat* src = (P.src ? P.src : P.data) + base + (long)j2 * P.estride + 2 * q;
+  const long rstep = (long)M0 * P.estride;
+  qfloat a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = *reinterpret_cast<const qfloat*>(src + k * rstep);
+  if (MODE == MVN_ST_FWD_MUL_INV) {
+    // the spectrum is stored in the digit-reversed row order the forward transform produces;
+    // fetched with the thread mapping of the last stage, used after the forward transform
+#pragma unroll
+    for (int it = 0; it < C::ITL; ++it) {
+      int w = tid + it * C::NT;
+      if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;  // clamped: loaded, never used
+      const int b = w / CH, qq = w % CH;
+      const cfloat* sp = P.spec + base + (long)(b * C::RL) * P.estride + 2 * qq;
+#pragma unroll
+      for (int k = 0; k < C::RL; ++k)
+        r.g[it * C::RL + k] = *reinterpret_cast<const qfloat*>(sp + k * P.estride);
+    }
+  }
+  cfloat tw[8];
+  fx_tw_row<8>(P.ax.tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
+  fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
+  fx_dft_q<8, -1>(a);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<-1>(tw[k]));
+  qfloat* d = reinterpret_cast<qfloat*>(buf) + j2 * C::TPQ + q;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k * M0 * C::TPQ] = a[k];
+}
+
+// inverse entry: global loads with the last stage's mapping, that stage (M = 1, no twiddles) in
+// registers
+template <int N>
+MVN_HD void fx_st_load_last(const StridedParams& P, long base, cfloat* buf, cfloat* tws, int tid) {
+  typedef FxStridedCfg<N> C;
+  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
+  const cfloat* src0 = (P.src ? P.src : P.data) + base;
+  qfloat a[ITL * RL];
+#pragma unroll
+  for (int it = 0; it < ITL; ++it) {
+    int w = tid + it * C::NT;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;
+    const int b = w / CH, q = w % CH;
+    const cfloat* src = src0 + (long)(b * RL) * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) a[it * RL + k] = *reinterpret_cast<const qfloat*>(src + k * P.estride);
+  }
+  fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
+#pragma unroll
+  for (int it = 0; it < ITL; ++it) {
+    const int w = tid + it * C::NT;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) break;
+    const int b = w / CH, q = w % CH;
+    fx_dft_q<RL, +1>(a + it * RL);
+    qfloat* d = reinterpret_cast<qfloat*>(buf) + (b * RL) * C::TPQ + q;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) d[k * C::TPQ] = a[it * RL + k];
+  }
+}
+
+// forward exit: last stage in registers, stored straight to global memory
+template <int N>
+MVN_HD void fx_st_last_store(const StridedParams& P, long base, const cfloat* buf, int tid) {
+  typedef FxStridedCfg<N> C;
+  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
+#pragma unroll
+  for (int it = 0; it < ITL; ++it) {
+    const int w = tid + it * C::NT;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) break;
+    const int b = w / CH, q = w % CH;
+    const qfloat* s = reinterpret_cast<const qfloat*>(buf) + (b * RL) * C::TPQ + q;
+    qfloat a[RL];
+#pragma unroll
+    for (int k = 0; k < RL; ++k) a[k] = s[k * C::TPQ];
+    fx_dft_q<RL, -1>(a);
+    cfloat* dst = P.data + base + (long)(b * RL) * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) *reinterpret_cast<qfloat*>(dst + k * P.estride) = a[k];
+  }
+}
+
+// fused pass, middle: last forward stage, times the PSF spectrum, first inverse stage
+template <int N>
+MVN_HD void fx_st_last_mul_last(cfloat* buf, FxStridedRegs<N>& r, int tid) {
+  typedef FxStridedCfg<N> C;
+  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
+#pragma unroll
+  for (int it = 0; it < ITL; ++it) {
+    const int w = tid + it * C::NT;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) break;
+    const int b = w / CH, q = w % CH;
+    qfloat* s = reinterpret_cast<qfloat*>(buf) + (b * RL) * C::TPQ + q;
+    qfloat a[RL];
+#pragma unroll
+    for (int k = 0; k < RL; ++k) a[k] = s[k * C::TPQ];
+    fx_dft_q<RL, -1>(a);
+#pragma unroll
+    for (int k = 0; k < RL; ++k) a[k] = fx_qmul_q(a[k], r.g[it * RL + k]);
+    fx_dft_q<RL, +1>(a);
+#pragma unroll
+    for (int k = 0; k < RL; ++k) s[k * C::TPQ] = a[k];
+  }
+}
+
+// inverse exit: stage 0 (twiddles first, decimation in time) in registers, stored to global
+template <int N>
+MVN_HD void fx_st_stage0_store(const StridedParams& P, long base, const cfloat* buf,
+                               const cfloat* tws, int tid) {
+  typedef FxStridedCfg<N> C;
+  constexpr int M0 = C::M0, CH = C::CH;
+  const int q = tid % CH, j2 = tid / CH;
+  const qfloat* s = reinterpret_cast<const qfloat*>(buf) + j2 * C::TPQ + q;
+  qfloat a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = s[k * M0 * C::TPQ];
+  cfloat tw[8];
+  fx_tw_row<8>(tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<+1>(tw[k]));
+  fx_dft_q<8, +1>(a);
+  cfloat* dst = P.data + base + (long)j2 * P.estride + 2 * q;
+  const long rstep = (long)M0 * P.estride;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) *reinterpret_cast<qfloat*>(dst + k * rstep) = a[k];
+}
+
+template <int N, int MODE, typename Ctx>
+MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx& ctx) {
+  typedef FxStridedCfg<N> C;
+  constexpr int T = C::T, NT = C::NT, NT_ = C::NT, NS = C::NS;
+  (void)NT_;
+  const long o = block / P.tiles_per_outer;
+  const int t = (int)(block - o * P.tiles_per_outer);
+  const long base = o * P.ostride + (long)t * T;
+  cfloat* buf = lds;
+  cfloat* tws = lds + N * C::TP;
+  if (MODE == MVN_ST_INV) {
+    MVN_PHASE(ctx, (fx_st_load_last<N>(P, base, buf, tws, tid)));
+    FxStagesQ<N, NT, +1, false, NS - 2, 1, Ctx>::run(buf, tws, ctx);
+    MVN_PHASE(ctx, (fx_st_stage0_store<N>(P, base, buf, tws, tid)));
+  } else {
+    MVN_PHASE(ctx, (fx_st_load_first<N, MODE>(P, base, buf, tws, r, tid)));
+    FxStagesQ<N, NT, -1, true, 1, NS - 2, Ctx>::run(buf, tws, ctx);
+    if (MODE == MVN_ST_FWD) {
+      MVN_PHASE(ctx, (fx_st_last_store<N>(P, base, buf, tid)));
+    } else {
+      MVN_PHASE(ctx, (fx_st_last_mul_last<N>(buf, r, tid)));
+      FxStagesQ<N, NT, +1, false, NS - 2, 1, Ctx>::run(buf, tws, ctx);
+      MVN_PHASE(ctx, (fx_st_stage0_store<N>(P, base, buf, tws, tid)));
+    }
+  }
+}
+#endif  // MVN_FX_STRIDED_V1
 
 // ---------------------------------------------------------------------------------------------
 // last-axis passes for even d2 = 2H, H a power of two; T rows per tile, transposed in LDS with

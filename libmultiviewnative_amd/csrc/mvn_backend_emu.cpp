@@ -159,21 +159,29 @@ static void emu_rows_fixed(const RowsParams& p, long ntiles, bool r2c) {
   }
 }
 
-template <int N>
-static void emu_strided_fixed(int mode, const StridedParams& p, long nblocks) {
-  typedef FxCtx<FxStridedRegs<N>, FxStridedCfg<N>::NT> Ctx;
+template <int N, int MODE>
+static void emu_strided_fixed_mode(const StridedParams& p0, long nblocks) {
+  typedef FxStridedSel<N, MODE> Sel;
+  typedef typename Sel::Ctx Ctx;
+  StridedParams p = p0;
+  p.nblocks = nblocks;
+  // a "grid" of about half as many workgroups as tiles, so that the tile loop and its
+  // prefetching are exercised (each workgroup walks over 1-2 tiles)
+  const long grid = nblocks > 1 ? (nblocks + 1) / 2 : 1;
 #pragma omp parallel
   {
     std::vector<char> lds(sizeof(cfloat) * FxStridedCfg<N>::lds_cfloats + 64);
     std::unique_ptr<Ctx> ctx(new Ctx());
 #pragma omp for schedule(static)
-    for (long b = 0; b < nblocks; ++b) {
-      cfloat* l = (cfloat*)lds.data();
-      if (mode == MVN_ST_FWD) fx_strided_body<N, MVN_ST_FWD>(p, b, l, *ctx);
-      if (mode == MVN_ST_INV) fx_strided_body<N, MVN_ST_INV>(p, b, l, *ctx);
-      if (mode == MVN_ST_FWD_MUL_INV) fx_strided_body<N, MVN_ST_FWD_MUL_INV>(p, b, l, *ctx);
-    }
+    for (long b = 0; b < grid; ++b) Sel::run(p, b, nblocks, grid, (cfloat*)lds.data(), *ctx);
   }
+}
+
+template <int N>
+static void emu_strided_fixed(int mode, const StridedParams& p, long nblocks) {
+  if (mode == MVN_ST_FWD) emu_strided_fixed_mode<N, MVN_ST_FWD>(p, nblocks);
+  if (mode == MVN_ST_INV) emu_strided_fixed_mode<N, MVN_ST_INV>(p, nblocks);
+  if (mode == MVN_ST_FWD_MUL_INV) emu_strided_fixed_mode<N, MVN_ST_FWD_MUL_INV>(p, nblocks);
 }
 
 static bool emu_rows_fixed_dispatch(const RowsParams& p, long ntiles, bool r2c) {

@@ -16,6 +16,8 @@
 // thread-to-data mapping.
 #pragma once
 
+#include <type_traits>
+
 #include "mvn_pass_bodies.hpp"
 
 #if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
@@ -52,11 +54,19 @@ struct FxCtx {
     __VA_ARGS__;                 \
   }                              \
   __syncthreads();
+#define MVN_PHASE_NOSYNC(ctx, ...) \
+  {                                \
+    const int tid = (ctx).tid;     \
+    auto& r = (ctx).regs;          \
+    (void)r;                       \
+    __VA_ARGS__;                   \
+  }
 #else
 template <typename Regs, int NT>
 struct FxCtx {
   Regs regs[NT];
 };
+#define MVN_PHASE_NOSYNC(ctx, ...) MVN_PHASE(ctx, __VA_ARGS__)
 #define MVN_PHASE(ctx, ...)                  \
   for (int tid = 0; tid < NT_; ++tid) {      \
     auto& r = (ctx).regs[tid];               \
@@ -222,113 +232,6 @@ constexpr int fx_pick_nt(int cap, int full, int a, int b, int c) {
   return 0;
 }
 
-#ifdef MVN_FX_STRIDED_V1
-// ---------------------------------------------------------------------------------------------
-// strided-axis pass, full tiles of T neighbouring bins (cstride == 1, ncols % T == 0)
-// ---------------------------------------------------------------------------------------------
-template <int N>
-struct FxStridedCfg {
-  // 128-byte row segments wherever the tile fits the LDS at all (two workgroups per CU up to
-  // N = 576, one beyond; measured: 64-byte segments cost 15-30 % of the pass at N = 640..1024)
-  static constexpr int T = N <= 1024 ? 16 : 8;
-  static constexpr int TP = T;
-  static constexpr int CH = T / 2;  // 16-byte chunks per tile row
-  // threads: whole tile rows per sweep (N * CH divisible by NT), not more than one radix-8
-  // butterfly each; 512 unless that leaves more than eight 16-byte loads per thread (long axes)
-  static constexpr int FULL = N * T / 8 >= 64 ? N * T / 8 : 64;
-  static constexpr int NT512 = fx_pick_nt(512, FULL, N * CH, N * CH, N * CH);
-  static constexpr int NT = (NT512 > 0 && N * CH / NT512 <= 8) ? NT512 : fx_pick_nt(1024, FULL, N * CH, N * CH, N * CH);
-  static constexpr int RPT = NT / CH;      // tile rows covered by one sweep of the workgroup
-  static constexpr int U = N / RPT;        // 16-byte loads per thread
-  static constexpr int lds_cfloats = N * TP + fx_twsize(N);
-  static_assert(fx_smooth(N) && N >= 64 && N <= 2048, "unsupported fixed length");
-  static_assert(NT >= 64 && N % RPT == 0, "tile rows must divide");
-  static_assert(sizeof(cfloat) * lds_cfloats <= 160 * 1024, "tile does not fit the LDS");
-};
-
-template <int N>
-struct FxStridedRegs {
-  qfloat v[FxStridedCfg<N>::U];
-  qfloat g[FxStridedCfg<N>::U];
-};
-
-// phase functions (plain functions so that loop pragmas are honoured; MVN_PHASE only calls them)
-template <int N, int MODE>
-MVN_HD void fx_st_load(const StridedParams& P, long base, cfloat* buf, cfloat* tws,
-                       FxStridedRegs<N>& r, int tid) {
-  typedef FxStridedCfg<N> C;
-  constexpr int TP = C::TP, U = C::U;
-  const long rstep = (long)C::RPT * P.estride;
-  const int q = tid % C::CH, jr = tid / C::CH;
-  const cfloat* src = (P.src ? P.src : P.data) + base + (long)jr * P.estride + 2 * q;
-#pragma unroll
-  for (int u = 0; u < U; ++u) r.v[u] = *reinterpret_cast<const qfloat*>(src + u * rstep);
-  if (MODE == MVN_ST_FWD_MUL_INV) {
-    // PSF-spectrum operands for the rows this thread multiplies later (the spectrum is stored
-    // in the same digit-reversed row order the forward transform produces); fetched now, used
-    // after the forward transform
-    const cfloat* sp = P.spec + base + (long)jr * P.estride + 2 * q;
-#pragma unroll
-    for (int u = 0; u < U; ++u) r.g[u] = *reinterpret_cast<const qfloat*>(sp + u * rstep);
-  }
-  fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int j = jr + u * C::RPT;
-    *reinterpret_cast<qfloat*>(buf + j * TP + 2 * q) = r.v[u];
-  }
-}
-
-template <int N>
-MVN_HD void fx_st_mul(cfloat* buf, FxStridedRegs<N>& r, int tid) {
-  typedef FxStridedCfg<N> C;
-  const int q = tid % C::CH, jr = tid / C::CH;
-#pragma unroll
-  for (int u = 0; u < C::U; ++u) {
-    qfloat* d = reinterpret_cast<qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q);
-    const qfloat a = *d;
-    const qfloat g = r.g[u];
-    *d = qmake(a.x * g.x - a.y * g.y, a.x * g.y + a.y * g.x, a.z * g.z - a.w * g.w,
-               a.z * g.w + a.w * g.z);
-  }
-}
-
-template <int N, int MODE>
-MVN_HD void fx_st_store(const StridedParams& P, long base, const cfloat* buf, int tid) {
-  typedef FxStridedCfg<N> C;
-  const int q = tid % C::CH, jr = tid / C::CH;
-  const long rstep = (long)C::RPT * P.estride;
-  cfloat* dst = P.data + base + (long)jr * P.estride + 2 * q;
-#pragma unroll
-  for (int u = 0; u < C::U; ++u)
-    *reinterpret_cast<qfloat*>(dst + u * rstep) =
-        *reinterpret_cast<const qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q);
-}
-
-template <int N, int MODE, typename Ctx>
-MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx& ctx) {
-  typedef FxStridedCfg<N> C;
-  constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
-  (void)NT_;
-  const long o = block / P.tiles_per_outer;
-  const int t = (int)(block - o * P.tiles_per_outer);
-  const long base = o * P.ostride + (long)t * T;
-  cfloat* buf = lds;
-  cfloat* tws = lds + N * TP;
-  MVN_PHASE(ctx, (fx_st_load<N, MODE>(P, base, buf, tws, r, tid)));
-  if (MODE == MVN_ST_INV) {
-    fx_dit<N, T, TP, false, NT, +1>(buf, tws, ctx);
-  } else {
-    fx_dif<N, T, TP, false, NT, -1>(buf, tws, ctx);
-    if (MODE == MVN_ST_FWD_MUL_INV) {
-      MVN_PHASE(ctx, (fx_st_mul<N>(buf, r, tid)));
-      fx_dit<N, T, TP, false, NT, +1>(buf, tws, ctx);
-    }
-  }
-  MVN_PHASE(ctx, (fx_st_store<N, MODE>(P, base, buf, tid)));
-}
-
-#else
 // ---------------------------------------------------------------------------------------------
 // strided-axis pass, full tiles of T neighbouring bins (cstride == 1, ncols % T == 0).
 //
@@ -343,6 +246,19 @@ MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx
 //   sequence.
 // That leaves ns-1 LDS round trips per transform (2 for N = 512; the fused pass 4 instead of 8).
 // ---------------------------------------------------------------------------------------------
+#ifndef MVN_FX_ST_NT_TARGET
+#define MVN_FX_ST_NT_TARGET 512
+#endif
+#ifndef MVN_FX_ST_MAX_WAVES
+#define MVN_FX_ST_MAX_WAVES 4
+#endif
+// stage-0 butterflies per thread: the fewest that bring the workgroup to <= target threads
+constexpr int fx_st_it0(int nt1, int target) {
+  for (int it = 1; it <= 8; ++it)
+    if (nt1 % it == 0 && (nt1 / it) % 64 == 0 && nt1 / it <= target) return it;
+  return 1;
+}
+
 template <int N>
 struct FxStridedCfg {
   // 128-byte row segments wherever the tile fits the LDS at all (two workgroups per CU up to
@@ -354,19 +270,30 @@ struct FxStridedCfg {
   static constexpr int NS = fx_nstages(N);
   static constexpr int R0 = fx_radix(N, 0), M0 = fx_M(N, 0);
   static constexpr int RL = fx_radix(N, NS - 1);  // radix of the last stage (M = 1)
-  static constexpr int NT = M0 * CH;              // one stage-0 butterfly (on two columns) per thread
-  static constexpr int NWL = (N / RL) * CH;       // work items of the last stage
+  // threads: NT1 = M0 * CH would give every thread one stage-0 butterfly (on two columns); IT0 of
+  // them per thread keep the workgroup at or below MVN_FX_ST_NT_TARGET threads, which leaves the
+  // registers for the tile fetched ahead (see fx_strided_body)
+  static constexpr int NT1 = M0 * CH;
+  static constexpr int IT0 = fx_st_it0(NT1, MVN_FX_ST_NT_TARGET);
+  static constexpr int NT = NT1 / IT0;
+  static constexpr int NWL = (N / RL) * CH;  // work items of the last stage
   static constexpr int ITL = (NWL + NT - 1) / NT;
   static constexpr int lds_cfloats = N * TP + fx_twsize(N);
+  // waves per SIMD the register allocation should leave room for: what the LDS admits, at most 4
+  static constexpr int WG_PER_CU = (160 * 1024) / (int)(sizeof(cfloat) * lds_cfloats) > 0 ? (160 * 1024) / (int)(sizeof(cfloat) * lds_cfloats) : 1;
+  static constexpr int WAVES_WANTED = (WG_PER_CU * (NT / 64) + 3) / 4;
+  static constexpr int WAVES = WAVES_WANTED > MVN_FX_ST_MAX_WAVES ? MVN_FX_ST_MAX_WAVES : WAVES_WANTED;
   static_assert(fx_smooth(N) && N >= 64 && N <= 2048 && N % 64 == 0, "unsupported fixed length");
   static_assert(R0 == 8 && NS >= 2 && M0 > 1 && fx_M(N, NS - 1) == 1, "unexpected radix plan");
-  static_assert(NT % 64 == 0 && NT <= 1024, "workgroup size");
+  static_assert(NT % 64 == 0 && NT <= 1024 && NT * IT0 == NT1, "workgroup size");
   static_assert(sizeof(cfloat) * lds_cfloats <= 160 * 1024, "tile does not fit the LDS");
 };
 
 template <int N>
 struct FxStridedRegs {
-  qfloat g[FxStridedCfg<N>::ITL * FxStridedCfg<N>::RL];  // PSF-spectrum operands (fused pass)
+  static constexpr int NF = 8 * FxStridedCfg<N>::IT0, NL = FxStridedCfg<N>::ITL * FxStridedCfg<N>::RL;
+  qfloat a[NF > NL ? NF : NL];  // the tile rows of this thread, fetched one tile ahead
+  qfloat g[NL];                 // PSF-spectrum operands (fused pass), fetched one tile ahead
 };
 
 // one radix-R butterfly on both complex halves of R 16-byte registers
@@ -453,73 +380,115 @@ struct FxStagesQ {
 };
 
 // phase functions (plain functions so that loop pragmas are honoured; MVN_PHASE only calls them)
+//
+// A workgroup walks over several tiles (block, block + step, ...).  The global loads of the NEXT
+// tile are issued as soon as the registers that receive them are free -- right after stage 0 /
+// the first inverse stage has been written to the LDS -- so they are in flight during the LDS
+// stages and the stores of the current tile (fused pass: see fx_st_first).
 
-// forward entry: global loads, stage 0 in registers (twiddles straight from the global table,
-// which the same phase copies to the LDS for the later stages), PSF operands prefetched
-template <int N, int MODE>
-MVN_HD void fx_st_load_first(const StridedParams& P, long base, cfloat* buf, cfloat* tws,
-                             FxStridedRegs<N>& r, int tid) {
-  typedef FxStridedCfg<N> C;
-  constexpr int M0 = C::M0, CH = C::CH;
-  const int q = tid % CH, j2 = tid / CH;
-  const cfloat* src = (P.src ? P.src : P.data) + base + (long)j2 * P.estride + 2 * q;
-  const long rstep = (long)M0 * P.estride;
-  qfloat a[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = *reinterpret_cast<const qfloat*>(src + k * rstep);
-  if (MODE == MVN_ST_FWD_MUL_INV) {
-    // the spectrum is stored in the digit-reversed row order the forward transform produces;
-    // fetched with the thread mapping of the last stage, used after the forward transform
-#pragma unroll
-    for (int it = 0; it < C::ITL; ++it) {
-      int w = tid + it * C::NT;
-      if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;  // clamped: loaded, never used
-      const int b = w / CH, qq = w % CH;
-      const cfloat* sp = P.spec + base + (long)(b * C::RL) * P.estride + 2 * qq;
-#pragma unroll
-      for (int k = 0; k < C::RL; ++k)
-        r.g[it * C::RL + k] = *reinterpret_cast<const qfloat*>(sp + k * P.estride);
-    }
-  }
-  cfloat tw[8];
-  fx_tw_row<8>(P.ax.tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
-  fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
-  fx_dft_q<8, -1>(a);
-#pragma unroll
-  for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<-1>(tw[k]));
-  qfloat* d = reinterpret_cast<qfloat*>(buf) + j2 * C::TPQ + q;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) d[k * M0 * C::TPQ] = a[k];
+template <int N>
+MVN_HD long fx_st_base(const StridedParams& P, long block) {
+  // launches have far fewer than 2^31 tiles (checked by the launcher): 32-bit division
+  const unsigned o = (unsigned)block / (unsigned)P.tiles_per_outer;
+  const unsigned t = (unsigned)block - o * (unsigned)P.tiles_per_outer;
+  return (long)o * P.ostride + (long)t * FxStridedCfg<N>::T;
 }
 
-// inverse entry: global loads with the last stage's mapping, that stage (M = 1, no twiddles) in
-// registers
+// tile rows with the mapping of stage 0: work item w = tid + it NT <-> rows j2 + k M0
 template <int N>
-MVN_HD void fx_st_load_last(const StridedParams& P, long base, cfloat* buf, cfloat* tws, int tid) {
+MVN_HD void fx_st_fetch_first(const StridedParams& P, long base, FxStridedRegs<N>& r, int tid) {
   typedef FxStridedCfg<N> C;
-  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
   const cfloat* src0 = (P.src ? P.src : P.data) + base;
-  qfloat a[ITL * RL];
+  const long rstep = (long)C::M0 * P.estride;
 #pragma unroll
-  for (int it = 0; it < ITL; ++it) {
+  for (int it = 0; it < C::IT0; ++it) {
+    const int w = tid + it * C::NT;
+    const int q = w % C::CH, j2 = w / C::CH;
+    const cfloat* src = src0 + (long)j2 * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.a[it * 8 + k] = *reinterpret_cast<const qfloat*>(src + k * rstep);
+  }
+}
+
+// rows of `from` with the mapping of the last stage: thread <-> rows b R + k (clamped work items
+// are loaded but never used)
+template <int N>
+MVN_HD void fx_st_fetch_last(const cfloat* from, const StridedParams& P, long base, qfloat* dst,
+                             int tid) {
+  typedef FxStridedCfg<N> C;
+#pragma unroll
+  for (int it = 0; it < C::ITL; ++it) {
     int w = tid + it * C::NT;
     if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;
-    const int b = w / CH, q = w % CH;
-    const cfloat* src = src0 + (long)(b * RL) * P.estride + 2 * q;
+    const int b = w / C::CH, q = w % C::CH;
+    const cfloat* src = from + base + (long)(b * C::RL) * P.estride + 2 * q;
 #pragma unroll
-    for (int k = 0; k < RL; ++k) a[it * RL + k] = *reinterpret_cast<const qfloat*>(src + k * P.estride);
+    for (int k = 0; k < C::RL; ++k)
+      dst[it * C::RL + k] = *reinterpret_cast<const qfloat*>(src + k * P.estride);
   }
+}
+
+// before the first tile: the twiddle table into the LDS, first tile's rows (and PSF operands)
+// requested
+template <int N, int MODE>
+MVN_HD void fx_st_prologue(const StridedParams& P, long base, cfloat* tws, FxStridedRegs<N>& r,
+                           int tid) {
+  typedef FxStridedCfg<N> C;
+  if (MODE == MVN_ST_INV)
+    fx_st_fetch_last<N>(P.src ? P.src : P.data, P, base, r.a, tid);
+  else
+    fx_st_fetch_first<N>(P, base, r, tid);
   fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
+}
+
+// forward entry: stage 0 in registers, then the next tile's rows are requested.  The fused pass
+// instead requests this tile's PSF operands first (they land during stage 0 and the inner
+// forward stages) and leaves the next tile's rows to the middle phase, when those registers are
+// free again: both sets ahead of time at once do not fit 128 registers.
+template <int N, int MODE>
+MVN_HD void fx_st_first(const StridedParams& P, long base, long next_base, bool has_next,
+                        cfloat* buf, const cfloat* tws, FxStridedRegs<N>& r, int tid) {
+  typedef FxStridedCfg<N> C;
+  if (MODE == MVN_ST_FWD_MUL_INV) fx_st_fetch_last<N>(P.spec, P, base, r.g, tid);
+#pragma unroll
+  for (int it = 0; it < C::IT0; ++it) {
+    const int w = tid + it * C::NT;
+    const int q = w % C::CH, j2 = w / C::CH;
+    qfloat a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = r.a[it * 8 + k];
+    cfloat tw[8];
+    fx_tw_row<8>(tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
+    fx_dft_q<8, -1>(a);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<-1>(tw[k]));
+    qfloat* d = reinterpret_cast<qfloat*>(buf) + j2 * C::TPQ + q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k * C::M0 * C::TPQ] = a[k];
+  }
+  if (MODE != MVN_ST_FWD_MUL_INV && has_next) fx_st_fetch_first<N>(P, next_base, r, tid);
+}
+
+// inverse entry: the last stage (M = 1, no twiddles) in registers
+template <int N>
+MVN_HD void fx_st_last_in(const StridedParams& P, long next_base, bool has_next, cfloat* buf,
+                          FxStridedRegs<N>& r, int tid) {
+  typedef FxStridedCfg<N> C;
+  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
 #pragma unroll
   for (int it = 0; it < ITL; ++it) {
     const int w = tid + it * C::NT;
     if (C::NWL % C::NT != 0 && w >= C::NWL) break;
     const int b = w / CH, q = w % CH;
-    fx_dft_q<RL, +1>(a + it * RL);
+    qfloat a[RL];
+#pragma unroll
+    for (int k = 0; k < RL; ++k) a[k] = r.a[it * RL + k];
+    fx_dft_q<RL, +1>(a);
     qfloat* d = reinterpret_cast<qfloat*>(buf) + (b * RL) * C::TPQ + q;
 #pragma unroll
-    for (int k = 0; k < RL; ++k) d[k * C::TPQ] = a[it * RL + k];
+    for (int k = 0; k < RL; ++k) d[k * C::TPQ] = a[k];
   }
+  if (has_next) fx_st_fetch_last<N>(P.src ? P.src : P.data, P, next_base, r.a, tid);
 }
 
 // forward exit: last stage in registers, stored straight to global memory
@@ -543,9 +512,12 @@ MVN_HD void fx_st_last_store(const StridedParams& P, long base, const cfloat* bu
   }
 }
 
-// fused pass, middle: last forward stage, times the PSF spectrum, first inverse stage
+// fused pass, middle: last forward stage, times the PSF spectrum (stored in the digit-reversed
+// row order the forward transform produces), first inverse stage; then the next tile's rows
+// are requested
 template <int N>
-MVN_HD void fx_st_last_mul_last(cfloat* buf, FxStridedRegs<N>& r, int tid) {
+MVN_HD void fx_st_last_mul_last(const StridedParams& P, long next_base, bool has_next, cfloat* buf,
+                                FxStridedRegs<N>& r, int tid) {
   typedef FxStridedCfg<N> C;
   constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
 #pragma unroll
@@ -564,6 +536,7 @@ MVN_HD void fx_st_last_mul_last(cfloat* buf, FxStridedRegs<N>& r, int tid) {
 #pragma unroll
     for (int k = 0; k < RL; ++k) s[k * C::TPQ] = a[k];
   }
+  if (has_next) fx_st_fetch_first<N>(P, next_base, r, tid);
 }
 
 // inverse exit: stage 0 (twiddles first, decimation in time) in registers, stored to global
@@ -572,49 +545,179 @@ MVN_HD void fx_st_stage0_store(const StridedParams& P, long base, const cfloat* 
                                const cfloat* tws, int tid) {
   typedef FxStridedCfg<N> C;
   constexpr int M0 = C::M0, CH = C::CH;
-  const int q = tid % CH, j2 = tid / CH;
-  const qfloat* s = reinterpret_cast<const qfloat*>(buf) + j2 * C::TPQ + q;
-  qfloat a[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = s[k * M0 * C::TPQ];
-  cfloat tw[8];
-  fx_tw_row<8>(tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
-#pragma unroll
-  for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<+1>(tw[k]));
-  fx_dft_q<8, +1>(a);
-  cfloat* dst = P.data + base + (long)j2 * P.estride + 2 * q;
   const long rstep = (long)M0 * P.estride;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) *reinterpret_cast<qfloat*>(dst + k * rstep) = a[k];
+  for (int it = 0; it < C::IT0; ++it) {
+    const int w = tid + it * C::NT;
+    const int q = w % CH, j2 = w / CH;
+    const qfloat* s = reinterpret_cast<const qfloat*>(buf) + j2 * C::TPQ + q;
+    qfloat a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = s[k * M0 * C::TPQ];
+    cfloat tw[8];
+    fx_tw_row<8>(tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<+1>(tw[k]));
+    fx_dft_q<8, +1>(a);
+    cfloat* dst = P.data + base + (long)j2 * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<qfloat*>(dst + k * rstep) = a[k];
+  }
 }
 
+// tiles first, first + step, ... < total
 template <int N, int MODE, typename Ctx>
-MVN_HD void fx_strided_body(const StridedParams& P, long block, cfloat* lds, Ctx& ctx) {
+MVN_HD void fx_strided_body(const StridedParams& P, long first, long total, long step, cfloat* lds,
+                            Ctx& ctx) {
   typedef FxStridedCfg<N> C;
-  constexpr int T = C::T, NT = C::NT, NT_ = C::NT, NS = C::NS;
+  constexpr int NT = C::NT, NT_ = C::NT, NS = C::NS;
   (void)NT_;
-  const long o = block / P.tiles_per_outer;
-  const int t = (int)(block - o * P.tiles_per_outer);
-  const long base = o * P.ostride + (long)t * T;
   cfloat* buf = lds;
   cfloat* tws = lds + N * C::TP;
-  if (MODE == MVN_ST_INV) {
-    MVN_PHASE(ctx, (fx_st_load_last<N>(P, base, buf, tws, tid)));
-    FxStagesQ<N, NT, +1, false, NS - 2, 1, Ctx>::run(buf, tws, ctx);
-    MVN_PHASE(ctx, (fx_st_stage0_store<N>(P, base, buf, tws, tid)));
-  } else {
-    MVN_PHASE(ctx, (fx_st_load_first<N, MODE>(P, base, buf, tws, r, tid)));
-    FxStagesQ<N, NT, -1, true, 1, NS - 2, Ctx>::run(buf, tws, ctx);
-    if (MODE == MVN_ST_FWD) {
-      MVN_PHASE(ctx, (fx_st_last_store<N>(P, base, buf, tid)));
-    } else {
-      MVN_PHASE(ctx, (fx_st_last_mul_last<N>(buf, r, tid)));
+  if (first >= total) return;
+  MVN_PHASE(ctx, (fx_st_prologue<N, MODE>(P, fx_st_base<N>(P, first), tws, r, tid)));
+  for (long block = first; block < total; block += step) {
+    const long base = fx_st_base<N>(P, block);
+    const bool has_next = block + step < total;
+    const long next_base = has_next ? fx_st_base<N>(P, block + step) : base;
+    if (MODE == MVN_ST_INV) {
+      MVN_PHASE(ctx, (fx_st_last_in<N>(P, next_base, has_next, buf, r, tid)));
       FxStagesQ<N, NT, +1, false, NS - 2, 1, Ctx>::run(buf, tws, ctx);
       MVN_PHASE(ctx, (fx_st_stage0_store<N>(P, base, buf, tws, tid)));
+    } else {
+      MVN_PHASE(ctx, (fx_st_first<N, MODE>(P, base, next_base, has_next, buf, tws, r, tid)));
+      FxStagesQ<N, NT, -1, true, 1, NS - 2, Ctx>::run(buf, tws, ctx);
+      if (MODE == MVN_ST_FWD) {
+        MVN_PHASE(ctx, (fx_st_last_store<N>(P, base, buf, tid)));
+      } else {
+        MVN_PHASE(ctx, (fx_st_last_mul_last<N>(P, next_base, has_next, buf, r, tid)));
+        FxStagesQ<N, NT, +1, false, NS - 2, 1, Ctx>::run(buf, tws, ctx);
+        MVN_PHASE(ctx, (fx_st_stage0_store<N>(P, base, buf, tws, tid)));
+      }
     }
   }
 }
-#endif  // MVN_FX_STRIDED_V1
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged variant of the fused FWD * PSF * INV pass, used where two or more workgroups share
+// a CU (tiles of at most half the LDS).  Every stage goes through the LDS with one column per work
+// item (fx_stage), which keeps the working set at ~50 registers; that leaves room to hold this
+// tile's PSF operands AND the next tile's rows in registers at 4 waves per SIMD -- the
+// register-staged body above spills when it tries (measured: 0.38 ms vs 0.35 ms at 512^3, and
+// 5.4 ms vs 3.0 ms on the 320-long axis of 320 x 1920 x 1920).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct FxFusedCfg {
+  typedef FxStridedCfg<N> S;
+  static constexpr bool USE = S::WG_PER_CU >= 2;
+  static constexpr int T = S::T, TP = S::TP, CH = S::CH;
+  // threads: whole tile rows per sweep (N * CH divisible by NT), not more than one radix-8
+  // butterfly each; 512 unless that leaves more than eight 16-byte loads per thread
+  static constexpr int FULL = N * T / 8 >= 64 ? N * T / 8 : 64;
+  static constexpr int NT512 = fx_pick_nt(512, FULL, N * CH, N * CH, N * CH);
+  static constexpr int NT = (NT512 > 0 && N * CH / NT512 <= 8) ? NT512 : fx_pick_nt(1024, FULL, N * CH, N * CH, N * CH);
+  static constexpr int RPT = NT / CH;  // tile rows covered by one sweep of the workgroup
+  static constexpr int U = N / RPT;    // 16-byte loads per thread
+  static constexpr int WAVES_WANTED = (S::WG_PER_CU * (NT / 64) + 3) / 4;
+  static constexpr int WAVES = WAVES_WANTED > MVN_FX_ST_MAX_WAVES ? MVN_FX_ST_MAX_WAVES : WAVES_WANTED;
+  static_assert(NT >= 64 && N % RPT == 0, "tile rows must divide");
+};
+
+template <int N>
+struct FxFusedRegs {
+  qfloat v[FxFusedCfg<N>::U];  // tile rows, fetched one tile ahead
+  qfloat g[FxFusedCfg<N>::U];  // PSF-spectrum operands of the current tile
+};
+
+// thread <-> 16-byte chunk q of rows jr + u RPT
+template <int N>
+MVN_HD void fx_fu_fetch(const cfloat* from, const StridedParams& P, long base, qfloat* dst, int tid) {
+  typedef FxFusedCfg<N> C;
+  const int q = tid % C::CH, jr = tid / C::CH;
+  const cfloat* src = from + base + (long)jr * P.estride + 2 * q;
+  const long rstep = (long)C::RPT * P.estride;
+#pragma unroll
+  for (int u = 0; u < C::U; ++u) dst[u] = *reinterpret_cast<const qfloat*>(src + u * rstep);
+}
+
+// tile entry: request this tile's PSF operands (the spectrum is stored in the digit-reversed row
+// order the forward transform produces, i.e. row for row what the LDS holds after it), put the
+// rows fetched ahead into the LDS, request the next tile's rows
+template <int N>
+MVN_HD void fx_fu_top(const StridedParams& P, long base, long next_base, bool has_next, cfloat* buf,
+                      FxFusedRegs<N>& r, int tid) {
+  typedef FxFusedCfg<N> C;
+  fx_fu_fetch<N>(P.spec, P, base, r.g, tid);
+  const int q = tid % C::CH, jr = tid / C::CH;
+#pragma unroll
+  for (int u = 0; u < C::U; ++u)
+    *reinterpret_cast<qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q) = r.v[u];
+  if (has_next) fx_fu_fetch<N>(P.src ? P.src : P.data, P, next_base, r.v, tid);
+}
+
+template <int N>
+MVN_HD void fx_fu_mul(cfloat* buf, FxFusedRegs<N>& r, int tid) {
+  typedef FxFusedCfg<N> C;
+  const int q = tid % C::CH, jr = tid / C::CH;
+#pragma unroll
+  for (int u = 0; u < C::U; ++u) {
+    qfloat* d = reinterpret_cast<qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q);
+    *d = fx_qmul_q(*d, r.g[u]);
+  }
+}
+
+template <int N>
+MVN_HD void fx_fu_store(const StridedParams& P, long base, const cfloat* buf, int tid) {
+  typedef FxFusedCfg<N> C;
+  const int q = tid % C::CH, jr = tid / C::CH;
+  const long rstep = (long)C::RPT * P.estride;
+  cfloat* dst = P.data + base + (long)jr * P.estride + 2 * q;
+#pragma unroll
+  for (int u = 0; u < C::U; ++u)
+    *reinterpret_cast<qfloat*>(dst + u * rstep) =
+        *reinterpret_cast<const qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q);
+}
+
+template <int N, typename Ctx>
+MVN_HD void fx_fused_lds_body(const StridedParams& P, long first, long total, long step,
+                              cfloat* lds, Ctx& ctx) {
+  typedef FxFusedCfg<N> C;
+  constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
+  (void)NT_;
+  cfloat* buf = lds;
+  cfloat* tws = lds + N * TP;
+  if (first >= total) return;
+  // the table is first read after the barrier that ends the tile-entry phase
+  MVN_PHASE_NOSYNC(ctx, (fx_fu_fetch<N>(P.src ? P.src : P.data, P, fx_st_base<N>(P, first), r.v, tid),
+                         fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(N), tid)));
+  for (long block = first; block < total; block += step) {
+    const long base = fx_st_base<N>(P, block);
+    const bool has_next = block + step < total;
+    const long next_base = has_next ? fx_st_base<N>(P, block + step) : base;
+    MVN_PHASE(ctx, (fx_fu_top<N>(P, base, next_base, has_next, buf, r, tid)));
+    fx_dif<N, T, TP, false, NT, -1>(buf, tws, ctx);
+    MVN_PHASE(ctx, (fx_fu_mul<N>(buf, r, tid)));
+    fx_dit<N, T, TP, false, NT, +1>(buf, tws, ctx);
+    MVN_PHASE(ctx, (fx_fu_store<N>(P, base, buf, tid)));
+  }
+}
+
+// which body, register block and workgroup size a (length, mode) pair uses
+template <int N, int MODE>
+struct FxStridedSel {
+  static constexpr bool LDS_FUSED = MODE == MVN_ST_FWD_MUL_INV && FxFusedCfg<N>::USE;
+  static constexpr int NT = LDS_FUSED ? FxFusedCfg<N>::NT : FxStridedCfg<N>::NT;
+  static constexpr int WAVES = LDS_FUSED ? FxFusedCfg<N>::WAVES : FxStridedCfg<N>::WAVES;
+  typedef typename std::conditional<LDS_FUSED, FxFusedRegs<N>, FxStridedRegs<N>>::type Regs;
+  typedef FxCtx<Regs, NT> Ctx;
+  static MVN_HD void run(const StridedParams& P, long first, long total, long step, cfloat* lds,
+                         Ctx& ctx) {
+    if constexpr (LDS_FUSED)
+      fx_fused_lds_body<N>(P, first, total, step, lds, ctx);
+    else
+      fx_strided_body<N, MODE>(P, first, total, step, lds, ctx);
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // last-axis passes for even d2 = 2H, H a power of two; T rows per tile, transposed in LDS with

@@ -476,6 +476,7 @@ struct StridedParams {
   long lds_tw;  // offset (in cfloat) of the LDS twiddle copy
   int is_nyq;   // launch works on the Nyquist plane (profiling tag only)
   int fixed;    // 1: launch the compile-time specialised kernel for this length (mvn_fixed.hpp)
+  long nblocks; // fixed kernels: tiles of the launch (a workgroup walks over several of them)
 };
 
 // Loads are issued in batches of U per thread BEFORE any of them is consumed, so a tile's HBM

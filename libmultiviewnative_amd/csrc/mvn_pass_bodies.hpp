@@ -69,13 +69,35 @@ MVN_HD float mvn_quotient_g(float view, float blurred, int guard) {
   return (guard && view == 0.f) ? 0.f : mvn_quotient(view, blurred);
 }
 
+// sqrt of a double >= 1 (the Tikhonov argument 1 + 2 lambda v with v > 0).  On the device this is
+// the compiler's own correctly rounded f64 expansion (rsq seed, two coupled Goldschmidt steps,
+// two residual corrections) minus its rescaling of tiny inputs and its zero / infinity fix-up,
+// neither of which can trigger for arguments >= 1: same bits, a third fewer instructions in the
+// VALU-bound update pass.  +inf comes out as NaN instead of +inf; the clamp that follows maps
+// both to minValue (inc/cpu_kernels.h:82-83).
+MVN_HD double mvn_sqrt_ge1(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MVN_HOST_EMU)
+  const double y = __builtin_amdgcn_rsq(x);
+  const double h0 = y * 0.5, s0 = x * y;
+  const double r0 = __builtin_fma(-h0, s0, 0.5);
+  const double s1 = __builtin_fma(s0, r0, s0);
+  const double h1 = __builtin_fma(h0, r0, h0);
+  const double d0 = __builtin_fma(-s1, s1, x);
+  const double s2 = __builtin_fma(d0, h1, s1);
+  const double d1 = __builtin_fma(-s2, s2, x);
+  return __builtin_fma(d1, h1, s2);
+#else
+  return sqrt(x);
+#endif
+}
+
 // clamp / regularise chain of inc/cpu_kernels.h:40-49 (lambda == 0) and :75-86 (lambda > 0)
 MVN_HD float mvn_next_value(float last, float integral, double lambda, float lambda_inv,
                             float min_value) {
   MVN_FP_EXACT
   float value = last * integral;
   if (value > 0.f) {
-    if (lambda > 0.) value = (float)((double)lambda_inv * (sqrt(1. + 2. * lambda * (double)value) - 1.));
+    if (lambda > 0.) value = (float)((double)lambda_inv * (mvn_sqrt_ge1(1. + 2. * lambda * (double)value) - 1.));
   } else {
     value = min_value;
   }

@@ -96,11 +96,12 @@ MVN_HD float mvn_next_value(float last, float integral, double lambda, float lam
                             float min_value) {
   MVN_FP_EXACT
   float value = last * integral;
-  if (value > 0.f) {
-    if (lambda > 0.) value = (float)((double)lambda_inv * (mvn_sqrt_ge1(1. + 2. * lambda * (double)value) - 1.));
-  } else {
-    value = min_value;
-  }
+  // the regularised value is formed for every lane and selected afterwards: no divergent branch
+  // around the f64 chain, so the chains of the 16 values a thread owns interleave (for
+  // value <= 0 or NaN it is garbage that the select drops)
+  float reg = value;
+  if (lambda > 0.) reg = (float)((double)lambda_inv * (mvn_sqrt_ge1(1. + 2. * lambda * (double)value) - 1.));
+  value = value > 0.f ? reg : min_value;
   float next;
   if (isnan(value) || isinf(value))
     next = min_value;

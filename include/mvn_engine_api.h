@@ -46,6 +46,17 @@ MVN_API int mvn_fft3_time(int device, const int dims[3], int direction, int reps
 MVN_API int mvn_fft3_profile(int device, const int dims[3], int direction, int reps, float* ms,
                              double* per_kind_ms);
 
+/* Batched transforms, the counterpart of the cufftPlanMany path of the reference's
+ * bench/bench_gpu_many_nd_fft.cu:403-463: `batch` stacks of one shape, contiguous in `real`
+ * ([batch][d0][d1][d2]), go through ONE cached plan back to back on one stream; `spec` receives
+ * [batch][d0][d1][d2/2+1] complex64 in natural bin order. */
+MVN_API int mvn_fft3_many_r2c(int device, const int dims[3], int batch, const float* real,
+                              float* spec);
+/* resident timing of the same sweep over `batch` stacks (direction 0 forward, 1 backward):
+ * *ms = average milliseconds per sweep over the batch, stacks already in HBM */
+MVN_API int mvn_fft3_many_time(int device, const int dims[3], int batch, int direction, int reps,
+                               float* ms);
+
 /* ---- resident RL engine ----------------------------------------------------------------- */
 MVN_API int mvn_engine_create(int device, const int dims[3], int num_views, mvn_engine** out);
 MVN_API int mvn_engine_destroy(mvn_engine* e);

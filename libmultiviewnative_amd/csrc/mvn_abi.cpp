@@ -788,6 +788,122 @@ int mvn_fft3_profile(int device, const int dims[3], int direction, int reps, flo
   });
 }
 
+// Batched transforms: `batch` stacks of one shape through ONE cached plan, back to back on one
+// stream -- the counterpart of the cufftPlanMany path of bench/bench_gpu_many_nd_fft.cu:403-463.
+namespace {
+struct FftBatch {
+  std::shared_ptr<Plan3D> plan;
+  be::stream_t s = nullptr;
+  std::vector<float*> vol;
+  std::vector<cfloat*> nyq;
+  FftBatch(int dev, const int* dims, int batch) {
+    be::set_device(dev);
+    plan = PlanStore::get().add(dev, to_shape(dims));
+    s = be::stream_create();
+    try {
+      for (int b = 0; b < batch; ++b) {
+        vol.push_back((float*)be::dmalloc(plan->main_bytes()));
+        be::dzero(vol.back(), plan->main_bytes(), s);
+        nyq.push_back(nullptr);
+        if (plan->nyq_bytes()) {
+          nyq.back() = (cfloat*)be::dmalloc(plan->nyq_bytes());
+          be::dzero(nyq.back(), plan->nyq_bytes(), s);
+        }
+      }
+    } catch (...) {
+      release();
+      throw;
+    }
+  }
+  void release() {
+    try {
+      be::stream_sync(s);
+    } catch (...) {
+    }
+    for (float* v : vol) be::dfree(v);
+    for (cfloat* n : nyq) be::dfree(n);
+    vol.clear();
+    nyq.clear();
+    if (s) be::stream_destroy(s);
+    s = nullptr;
+  }
+  ~FftBatch() { release(); }
+};
+}  // namespace
+
+int mvn_fft3_many_r2c(int device, const int dims[3], int batch, const float* real, float* spec) {
+  return guarded("mvn_fft3_many_r2c", [&] {
+    if (batch < 1 || !real || !spec) throw std::invalid_argument("bad batch or null buffers");
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    FftBatch f(dev, dims, batch);
+    const Layout& L = f.plan->L;
+    const size_t nreal = (size_t)L.d0 * L.d1 * L.d2;
+    const int nc = L.d2 / 2 + 1;
+    const size_t nspec = (size_t)L.d0 * L.d1 * nc;
+    for (int b = 0; b < batch; ++b)
+      be::h2d_2d(f.vol[b], (size_t)L.RP * 4, real + b * nreal, (size_t)L.d2 * 4, (size_t)L.d2 * 4,
+                 L.rows, f.s);
+    for (int b = 0; b < batch; ++b) f.plan->forward(f.vol[b], f.nyq[b], f.s);
+    std::vector<cfloat> main_h(L.rows * (size_t)L.C), nyq_h(L.nyq_cplx());
+    const std::vector<int>& i0 = f.plan->ax0.host.inv;
+    const std::vector<int>& i1 = f.plan->ax1.host.inv;
+    const std::vector<int>& i2 = f.plan->ax2.host.inv;
+    for (int b = 0; b < batch; ++b) {
+      be::d2h(main_h.data(), f.vol[b], main_h.size() * sizeof(cfloat), f.s);
+      if (L.even) be::d2h(nyq_h.data(), f.nyq[b], nyq_h.size() * sizeof(cfloat), f.s);
+      be::stream_sync(f.s);
+      cfloat* out = reinterpret_cast<cfloat*>(spec) + b * nspec;
+      for (int k0 = 0; k0 < L.d0; ++k0)
+        for (int k1 = 0; k1 < L.d1; ++k1) {
+          const size_t srow = (size_t)i0[k0] * L.d1 + (size_t)i1[k1];
+          cfloat* o = out + ((size_t)k0 * L.d1 + k1) * (size_t)nc;
+          for (int k2 = 0; k2 < L.C; ++k2) o[k2] = main_h[srow * L.C + (L.even ? i2[k2] : k2)];
+          if (L.even) o[L.C] = nyq_h[srow];
+        }
+    }
+  });
+}
+
+int mvn_fft3_many_time(int device, const int dims[3], int batch, int direction, int reps,
+                       float* ms) {
+  return guarded("mvn_fft3_many_time", [&] {
+    if (batch < 1 || reps < 1 || !ms) throw std::invalid_argument("bad batch, reps or null ms");
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    FftBatch f(dev, dims, batch);
+    const Layout& L = f.plan->L;
+    {
+      std::vector<float> host(L.real_floats());
+      unsigned x = 12345u;
+      for (size_t i = 0; i < host.size(); ++i) {
+        x = x * 1664525u + 1013904223u;
+        host[i] = (float)(x >> 8) * (1.0f / 16777216.0f) - 0.5f;
+      }
+      for (int b = 0; b < batch; ++b) be::h2d(f.vol[b], host.data(), host.size() * 4, f.s);
+      be::stream_sync(f.s);
+    }
+    const float keep = 1.0f / (float)L.logical();
+    auto sweep = [&] {
+      for (int b = 0; b < batch; ++b) {
+        if (direction == 0)
+          f.plan->forward(f.vol[b], f.nyq[b], f.s);
+        else
+          f.plan->backward(f.vol[b], f.nyq[b], keep, f.s);
+      }
+    };
+    sweep();  // warm-up
+    be::event_t a = be::event_create(), b2 = be::event_create();
+    be::event_record(a, f.s);
+    for (int i = 0; i < reps; ++i) sweep();
+    be::event_record(b2, f.s);
+    be::event_sync(b2);
+    *ms = be::event_elapsed_ms(a, b2) / (float)reps;
+    be::event_destroy(a);
+    be::event_destroy(b2);
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // resident engine
 // ---------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ REFERENCE_ABI_SYMBOLS = [
 ENGINE_ABI_SYMBOLS = [
     "mvn_last_error", "mvn_backend_name", "mvn_release_cached_engines", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
-    "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_engine_create", "mvn_engine_destroy",
+    "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
     "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
     "mvn_engine_bind_delta", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
@@ -90,6 +90,8 @@ class Binding:
         l.mvn_fft3_time.argtypes = [C.c_int, i3, C.c_int, C.c_int, C.POINTER(C.c_float)]
         l.mvn_fft3_profile.argtypes = [C.c_int, i3, C.c_int, C.c_int, C.POINTER(C.c_float),
                                        C.POINTER(C.c_double)]
+        l.mvn_fft3_many_r2c.argtypes = [C.c_int, i3, C.c_int, c_float_p, c_float_p]
+        l.mvn_fft3_many_time.argtypes = [C.c_int, i3, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         l.mvn_engine_create.argtypes = [C.c_int, i3, C.c_int, C.POINTER(C.c_void_p)]
         l.mvn_engine_destroy.argtypes = [C.c_void_p]
         l.mvn_engine_set_view.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, i3,
@@ -184,6 +186,20 @@ class Binding:
     def fft3_time(self, shape, direction=0, reps=10, device=0):
         ms = C.c_float(0)
         self.check(self.l.mvn_fft3_time(device, _dims(shape), direction, reps, C.byref(ms)))
+        return ms.value
+
+    def rfft3_many(self, stacks, device=0):
+        """Forward r2c transform of [batch][d0][d1][d2] stacks through one plan."""
+        x = np.ascontiguousarray(stacks, dtype=np.float32)
+        batch, d0, d1, d2 = x.shape
+        out = np.empty((batch, d0, d1, d2 // 2 + 1), np.complex64)
+        self.check(self.l.mvn_fft3_many_r2c(device, _dims((d0, d1, d2)), batch, fptr(x),
+                                            out.ctypes.data_as(c_float_p)))
+        return out
+
+    def fft3_many_time(self, shape, batch, direction=0, reps=5, device=0):
+        ms = C.c_float(0)
+        self.check(self.l.mvn_fft3_many_time(device, _dims(shape), batch, direction, reps, C.byref(ms)))
         return ms.value
 
     def fft3_profile(self, shape, direction=0, reps=10, device=0):

@@ -395,3 +395,17 @@ def test_iterate_fft_legacy_steps(emu, shape, kshape):
          / np.float64(lf)).astype(np.float32)
     got = emu.iterate_fft(image, kernel, 1e-3, 0.006)
     assert np.abs(got - t).max() <= 2e-6 * np.abs(t).max()
+
+
+def test_batched_forward_matches_single_and_numpy(emu):
+    # bench/bench_gpu_many_nd_fft.cu:403-463: V stacks of one shape through one plan
+    rng = np.random.default_rng(11)
+    for shape in ((8, 12, 10), (16, 16, 18), (5, 6, 7)):
+        stacks = rng.standard_normal((3,) + shape).astype(np.float32)
+        many = emu.rfft3_many(stacks)
+        assert many.shape == (3,) + shape[:2] + (shape[2] // 2 + 1,)
+        for b in range(3):
+            assert np.array_equal(many[b], emu.rfft3(stacks[b]))
+            ref = np.fft.rfftn(stacks[b].astype(np.float64))
+            assert np.abs(many[b] - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert emu.fft3_many_time((8, 8, 8), 2, 0, 1) >= 0.0

@@ -23,6 +23,13 @@ MVN_API const char* mvn_backend_name(void);
 /* inplace_gpu_deconvolve keeps one resident engine per device between calls (same shape and view
  * count are re-used without re-allocating; MVN_ENGINE_CACHE=0 disables it).  This frees them. */
 MVN_API int mvn_release_cached_engines(void);
+/* A resident engine keeps, per view slot, the PSF spectra of the last call together with host
+ * copies of the kernels they were made from; a call (or mvn_engine_set_view) that brings
+ * bytewise identical kernels for a slot re-uses the spectra (the reference's
+ * GPU path recomputes them for every view and iteration, inc/gpu_convolve.cuh:121-124).
+ * MVN_PSF_CACHE=0 disables it.  out[0] = spectra re-used, out[1] = spectra prepared, both since
+ * process start. */
+MVN_API int mvn_psf_cache_counters(long out[2]);
 
 /* ---- plan_store (inc/plan_store.cuh: get()/add/has_key/empty/size/clear) ---------------- */
 MVN_API int mvn_plan_store_add(int device, const int dims[3]);

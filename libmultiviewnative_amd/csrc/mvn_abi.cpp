@@ -607,6 +607,14 @@ int mvn_release_cached_engines(void) {
   });
 }
 
+int mvn_psf_cache_counters(long out[2]) {
+  return guarded("mvn_psf_cache_counters", [&] {
+    if (!out) throw std::invalid_argument("null out");
+    out[0] = Engine::psf_cache_hits();
+    out[1] = Engine::psf_cache_misses();
+  });
+}
+
 int mvn_plan_store_add(int device, const int dims[3]) {
   return guarded("mvn_plan_store_add", [&] { PlanStore::get().add(pick_device(device), to_shape(dims)); });
 }

@@ -1,6 +1,10 @@
 // mvn_engine.cpp -- see mvn_engine.hpp
 #include "mvn_engine.hpp"
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 #include "mvn_fixed_geom.hpp"
 
 #include <cstdio>
@@ -597,6 +601,33 @@ void Engine::alloc_view(ViewSlot& s) {
   }
 }
 
+static std::atomic<long> g_psf_hits{0}, g_psf_misses{0};
+long Engine::psf_cache_hits() { return g_psf_hits.load(); }
+long Engine::psf_cache_misses() { return g_psf_misses.load(); }
+
+// The spectra of a slot stay valid for as long as the engine (shape, scale and layout are fixed
+// per engine): compare the incoming kernel with the host copy of the one they were made from.
+// A bytewise comparison of ~100 kB, not a hash: a false match would silently change results.
+// MVN_PSF_CACHE=0 always prepares.
+bool Engine::psf_resident(ViewSlot& s, int i, const float* kernel, const int* kdims) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("MVN_PSF_CACHE");
+    return !(e && std::strcmp(e, "0") == 0);
+  }();
+  const size_t n = (size_t)kdims[0] * (size_t)kdims[1] * (size_t)kdims[2];
+  const bool same = enabled && s.set && s.kcopy[i].size() == n && s.kdims[i][0] == kdims[0] &&
+                    s.kdims[i][1] == kdims[1] && s.kdims[i][2] == kdims[2] &&
+                    std::memcmp(s.kcopy[i].data(), kernel, n * sizeof(float)) == 0;
+  if (same) {
+    ++g_psf_hits;
+    return true;
+  }
+  ++g_psf_misses;
+  s.kcopy[i].assign(kernel, kernel + n);
+  for (int d = 0; d < 3; ++d) s.kdims[i][d] = kdims[d];
+  return false;
+}
+
 void Engine::set_view(int v, const float* image, const float* weights, const float* kernel1,
                       const int* k1dims, const float* kernel2, const int* k2dims) {
   if (v < 0 || v >= (int)views_.size()) throw std::out_of_range("mvn: view index");
@@ -611,6 +642,7 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
   float* specs[2] = {s.spec1, s.spec2};
   cfloat* nyqs[2] = {s.nyq1, s.nyq2};
   for (int i = 0; i < 2; ++i) {
+    if (psf_resident(s, i, ks[i], kd[i])) continue;
     const size_t kb = sizeof(float) * (size_t)kd[i][0] * (size_t)kd[i][1] * (size_t)kd[i][2];
     float* dk = (float*)be::dmalloc(kb);
     be::h2d(dk, ks[i], kb, stream_);
@@ -619,6 +651,7 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
     } catch (...) {
       be::stream_sync(stream_);
       be::dfree(dk);
+      s.kcopy[i].clear();  // the spectrum is in an unknown state
       throw;
     }
     be::stream_sync(stream_);
@@ -651,6 +684,7 @@ void Engine::stage_view(int v, const float* image, const float* weights, const f
   float* specs[2] = {s.spec1, s.spec2};
   cfloat* nyqs[2] = {s.nyq1, s.nyq2};
   for (int i = 0; i < 2; ++i) {
+    if (psf_resident(s, i, ks[i], kd[i])) continue;
     const size_t kb = sizeof(float) * (size_t)kd[i][0] * (size_t)kd[i][1] * (size_t)kd[i][2];
     float* dk = (float*)be::dmalloc(kb);
     stage_scratch_.push_back(dk);  // freed in finish_staging(), after the stream has drained

@@ -182,6 +182,10 @@ struct ViewSlot {
   float* spec2 = nullptr;
   cfloat* nyq2 = nullptr;
   bool set = false;
+  // host copies of the kernels whose spectra spec1 / spec2 currently hold: a later call that
+  // brings the same PSF for this slot (Fiji's block-after-block calls do) skips the preparation
+  std::vector<float> kcopy[2];
+  int kdims[2][3] = {{0, 0, 0}, {0, 0, 0}};
 };
 
 class Engine {
@@ -238,8 +242,13 @@ class Engine {
     work_has_psi_spectrum_ = false;
   }
   void sync();
+  // PSF spectra re-used / prepared since process start (all engines)
+  static long psf_cache_hits();
+  static long psf_cache_misses();
 
  private:
+  // true when slot spectrum i already belongs to this kernel; otherwise records the kernel
+  bool psf_resident(ViewSlot& s, int i, const float* kernel, const int* kdims);
   void conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate,
                  bool feed_next);
   void upload_volume(float* dst, const float* host, be::stream_t s);

@@ -28,7 +28,7 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_release_cached_engines", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
@@ -151,6 +151,11 @@ class Binding:
         self.l.compute_final_values(fptr(psi), fptr(integral), fptr(weight), psi.size, min_value,
                                     lambda_, device)
         return psi
+
+    def psf_cache_counters(self):
+        out = (C.c_long * 2)()
+        self.check(self.l.mvn_psf_cache_counters(out))
+        return int(out[0]), int(out[1])
 
     def iterate_fft(self, image, kernel, min_value=1e-4, lambda_=None, device=0):
         """iterate_fft_plain (lambda_ None; the reference fixes minValue = 1e-4 there) or

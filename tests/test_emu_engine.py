@@ -409,3 +409,34 @@ def test_batched_forward_matches_single_and_numpy(emu):
             ref = np.fft.rfftn(stacks[b].astype(np.float64))
             assert np.abs(many[b] - ref).max() <= 2e-5 * np.abs(ref).max()
     assert emu.fft3_many_time((8, 8, 8), 2, 0, 1) >= 0.0
+
+
+def test_psf_spectra_reused_across_calls(emu):
+    # block-after-block calls with the same PSFs re-use the resident spectra;
+    # a changed kernel invalidates exactly its own spectrum
+    shape = (12, 10, 16)
+    rng = np.random.default_rng(5)
+    _, views, k1, k2, w, _ = realistic_views(shape, 2, (5, 5, 5), seed=9)
+    emu.l.mvn_release_cached_engines()
+
+    def run(vs, a, b):
+        h = WorkspaceHolder(vs, a, b, w, lambda_=0.006, min_value=1e-4, iterations=2)
+        psi0 = np.full(shape, np.float32(vs[0].mean()), np.float32)
+        got = emu.gpu_deconvolve(psi0, h)
+        ref = orc.cpu_deconvolve(psi0, h, 2)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+    h0, m0 = emu.psf_cache_counters()
+    run(views, k1, k2)
+    h1, m1 = emu.psf_cache_counters()
+    assert (h1 - h0, m1 - m0) == (0, 4)
+    other = [(v * rng.uniform(0.5, 1.5, shape)).astype(np.float32) for v in views]
+    run(other, k1, k2)  # new stacks, same PSFs: every spectrum re-used
+    h2, m2 = emu.psf_cache_counters()
+    assert (h2 - h1, m2 - m1) == (4, 0)
+    k1b = [k.copy() for k in k1]
+    k1b[1][0, 0, 0] += np.float32(1e-3)
+    run(other, k1b, k2)  # one kernel differs in one tap: prepared again, the other three re-used
+    h3, m3 = emu.psf_cache_counters()
+    assert (h3 - h2, m3 - m2) == (3, 1)
+    emu.l.mvn_release_cached_engines()

@@ -98,4 +98,51 @@ MVN_API const char* mvn_kernel_kind_name(int kind);
 /* algorithmic bytes B = 4*d0*d1*2(d2/2+1) of the engine's shape */
 MVN_API size_t mvn_engine_B(mvn_engine* e);
 
+/* ---- slab-decomposed engine: the SEQUENTIAL sweep on several GPUs ------
+ * Rank `rank` of `nranks` keeps planes [rank*d0/nranks, (rank+1)*d0/nranks) of psi, of every
+ * view and of every weight stack; all host arrays below are those slabs, dense
+ * [d0/nranks][d1][d2] (kernels are passed whole).  The reference has no multi-GPU code
+ * (src/gpu_deconvolve_methods.cuh runs one device); the arithmetic is the view-after-view sweep
+ * of src/multiviewnative.cpp:191-227, pass for pass.
+ *
+ * Last-axis and dim1 passes are plane-local; the dim0 pass needs whole lines, so every
+ * convolution exchanges the half-transformed slab twice.  The exchange is the CALLER's (one
+ * all-to-all with equal splits per buffer, e.g. torch.distributed.all_to_all_single over RCCL):
+ *
+ *   for conv in (0, 1):                       conv 0: psi (*) kernel1, conv 1: quotient (*) kernel2
+ *     mvn_slab_pack(h, v, conv)               ... fills A_main / A_nyq
+ *     mvn_slab_sync(h); all-to-all A_main -> B_main and A_nyq -> B_nyq
+ *     mvn_slab_mid(h, v, conv)                dim0 forward * PSF * inverse, in place on B
+ *     mvn_slab_sync(h); all-to-all B_main -> A_main and B_nyq -> A_nyq
+ *     mvn_slab_unpack(h, v, conv, lambda, minValue, feed_next)
+ *                                             conv 0: view / blurred; conv 1: psi update
+ *
+ * Buffers hold main_floats / nyq_floats floats (nyq_floats == 0 for odd d2) and are split in
+ * `nranks` equal contiguous parts by the all-to-all.  feed_next != 0 says another view update
+ * follows (the update pass then leaves psi's last-axis transform for it).  Needs d0 and d1
+ * divisible by nranks with quotients >= 2. */
+typedef struct mvn_slab mvn_slab; /* opaque */
+MVN_API int mvn_slab_create(int device, const int dims[3], int nranks, int rank, int num_views,
+                            mvn_slab** out);
+MVN_API int mvn_slab_destroy(mvn_slab* h);
+MVN_API int mvn_slab_set_view(mvn_slab* h, int v, const float* image_slab,
+                              const float* weights_slab, const float* kernel1,
+                              const int k1dims[3], const float* kernel2, const int k2dims[3]);
+MVN_API int mvn_slab_set_psi(mvn_slab* h, const float* psi_slab);
+MVN_API int mvn_slab_get_psi(mvn_slab* h, float* psi_slab);
+MVN_API int mvn_slab_buffer_sizes(mvn_slab* h, size_t* main_floats, size_t* nyq_floats);
+/* device pointers of the exchange buffers; bind caller-owned device memory (e.g. torch tensors)
+ * so that a collective library can work on them in place, all-null returns to engine-owned */
+MVN_API int mvn_slab_buffers(mvn_slab* h, void** a_main, void** b_main, void** a_nyq,
+                             void** b_nyq);
+MVN_API int mvn_slab_bind_buffers(mvn_slab* h, void* a_main, void* b_main, void* a_nyq,
+                                  void* b_nyq);
+MVN_API int mvn_slab_begin(mvn_slab* h); /* psi was replaced: forget its cached transform */
+MVN_API int mvn_slab_pack(mvn_slab* h, int v, int conv);
+MVN_API int mvn_slab_mid(mvn_slab* h, int v, int conv);
+MVN_API int mvn_slab_unpack(mvn_slab* h, int v, int conv, double lambda, float min_value,
+                            int feed_next);
+MVN_API int mvn_slab_sync(mvn_slab* h);
+MVN_API int mvn_slab_stream(mvn_slab* h, void** hip_stream);
+
 #endif

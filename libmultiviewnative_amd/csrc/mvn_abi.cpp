@@ -24,6 +24,10 @@ struct mvn_engine {
   std::unique_ptr<Engine> impl;
 };
 
+struct mvn_slab {
+  std::unique_ptr<SlabEngine> impl;
+};
+
 static thread_local std::string g_last_error;
 
 static bool trace_on() {
@@ -1029,5 +1033,103 @@ int mvn_kernel_kind_count(void) { return KK_COUNT; }
 const char* mvn_kernel_kind_name(int kind) { return kernel_kind_name(kind); }
 
 size_t mvn_engine_B(mvn_engine* e) { return (e && e->impl) ? e->impl->layout().B() : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// slab-decomposed engine (sequential sweep across several GPUs)
+// ---------------------------------------------------------------------------------------------
+int mvn_slab_create(int device, const int dims[3], int nranks, int rank, int num_views,
+                    mvn_slab** out) {
+  return guarded("mvn_slab_create", [&] {
+    if (!out || !dims) throw std::invalid_argument("null argument");
+    *out = nullptr;
+    std::unique_ptr<mvn_slab> h(new mvn_slab());
+    h->impl.reset(new SlabEngine(pick_device(device), to_shape(dims), nranks, rank, num_views));
+    *out = h.release();
+  });
+}
+
+int mvn_slab_destroy(mvn_slab* e) {
+  return guarded("mvn_slab_destroy", [&] { delete e; });
+}
+
+#define MVN_SLAB_CALL(name, ...)                                        \
+  return guarded(name, [&] {                                            \
+    if (!e || !e->impl) throw std::invalid_argument("null slab engine"); \
+    SlabEngine& E = *e->impl;                                           \
+    (void)E;                                                            \
+    __VA_ARGS__;                                                        \
+  })
+
+int mvn_slab_set_view(mvn_slab* e, int v, const float* image_slab, const float* weights_slab,
+                      const float* kernel1, const int k1dims[3], const float* kernel2,
+                      const int k2dims[3]) {
+  MVN_SLAB_CALL("mvn_slab_set_view", {
+    if (!image_slab || !weights_slab || !kernel1 || !kernel2 || !k1dims || !k2dims)
+      throw std::invalid_argument("null argument");
+    E.set_view(v, image_slab, weights_slab, kernel1, k1dims, kernel2, k2dims);
+  });
+}
+
+int mvn_slab_set_psi(mvn_slab* e, const float* psi_slab) {
+  MVN_SLAB_CALL("mvn_slab_set_psi", {
+    if (!psi_slab) throw std::invalid_argument("null argument");
+    E.set_psi(psi_slab);
+  });
+}
+
+int mvn_slab_get_psi(mvn_slab* e, float* psi_slab) {
+  MVN_SLAB_CALL("mvn_slab_get_psi", {
+    if (!psi_slab) throw std::invalid_argument("null argument");
+    E.get_psi(psi_slab);
+  });
+}
+
+int mvn_slab_buffer_sizes(mvn_slab* e, size_t* main_floats, size_t* nyq_floats) {
+  MVN_SLAB_CALL("mvn_slab_buffer_sizes", {
+    if (main_floats) *main_floats = E.main_floats();
+    if (nyq_floats) *nyq_floats = E.nyq_floats();
+  });
+}
+
+int mvn_slab_bind_buffers(mvn_slab* e, void* a_main, void* b_main, void* a_nyq, void* b_nyq) {
+  MVN_SLAB_CALL("mvn_slab_bind_buffers",
+                E.bind_buffers((float*)a_main, (float*)b_main, (float*)a_nyq, (float*)b_nyq));
+}
+
+int mvn_slab_buffers(mvn_slab* e, void** a_main, void** b_main, void** a_nyq, void** b_nyq) {
+  MVN_SLAB_CALL("mvn_slab_buffers", {
+    if (a_main) *a_main = E.a_main();
+    if (b_main) *b_main = E.b_main();
+    if (a_nyq) *a_nyq = E.a_nyq();
+    if (b_nyq) *b_nyq = E.b_nyq();
+  });
+}
+
+int mvn_slab_begin(mvn_slab* e) { MVN_SLAB_CALL("mvn_slab_begin", E.begin_sweeps()); }
+int mvn_slab_pack(mvn_slab* e, int v, int conv) {
+  MVN_SLAB_CALL("mvn_slab_pack", {
+    if (conv != 0 && conv != 1) throw std::invalid_argument("conv must be 0 or 1");
+    E.step_pack(v, conv);
+  });
+}
+int mvn_slab_mid(mvn_slab* e, int v, int conv) {
+  MVN_SLAB_CALL("mvn_slab_mid", {
+    if (conv != 0 && conv != 1) throw std::invalid_argument("conv must be 0 or 1");
+    E.step_mid(v, conv);
+  });
+}
+int mvn_slab_unpack(mvn_slab* e, int v, int conv, double lambda, float min_value, int feed_next) {
+  MVN_SLAB_CALL("mvn_slab_unpack", {
+    if (conv != 0 && conv != 1) throw std::invalid_argument("conv must be 0 or 1");
+    E.step_unpack(v, conv, lambda, min_value, feed_next != 0);
+  });
+}
+int mvn_slab_sync(mvn_slab* e) { MVN_SLAB_CALL("mvn_slab_sync", E.sync()); }
+int mvn_slab_stream(mvn_slab* e, void** hip_stream) {
+  MVN_SLAB_CALL("mvn_slab_stream", {
+    if (!hip_stream) throw std::invalid_argument("null argument");
+    *hip_stream = (void*)E.stream();
+  });
+}
 
 }  // extern "C"

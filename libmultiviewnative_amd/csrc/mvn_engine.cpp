@@ -903,4 +903,258 @@ void Engine::sync() {
   prof_.collect();
 }
 
+// ---------------------------------------------------------------------------------------------
+// SlabEngine
+// ---------------------------------------------------------------------------------------------
+SlabEngine::SlabEngine(int device, const shape_t& dims, int nranks, int rank, int num_views)
+    : device_(device), P_(nranks), rank_(rank), dims_(dims) {
+  if (num_views < 1) throw std::invalid_argument("mvn: num_views must be >= 1");
+  if (nranks < 1 || rank < 0 || rank >= nranks) throw std::invalid_argument("mvn: bad rank / nranks");
+  if (dims[0] % nranks || dims[1] % nranks || dims[0] / nranks < 2 || dims[1] / nranks < 2)
+    throw std::invalid_argument("mvn: slab mode needs d0 and d1 divisible by the rank count, "
+                                "with at least two planes / rows per rank");
+  be::set_device(device_);
+  shape_t a = {{dims[0] / nranks, dims[1], dims[2]}};
+  shape_t b = {{dims[0], dims[1] / nranks, dims[2]}};
+  planA_ = PlanStore::get().add(device_, a);
+  planB_ = PlanStore::get().add(device_, b);
+  stream_ = be::stream_create();
+  const size_t mb = planA_->main_bytes(), nb = planA_->nyq_bytes();
+  psi_ = (float*)be::dmalloc(mb);
+  work_ = (float*)be::dmalloc(mb);
+  own_a_ = (float*)be::dmalloc(mb);
+  own_b_ = (float*)be::dmalloc(mb);
+  be::dzero(psi_, mb, stream_);
+  be::dzero(work_, mb, stream_);
+  if (nb) {
+    work_nyq_ = (cfloat*)be::dmalloc(nb);
+    own_an_ = (cfloat*)be::dmalloc(nb);
+    own_bn_ = (cfloat*)be::dmalloc(nb);
+  }
+  a_main_ = own_a_;
+  b_main_ = own_b_;
+  a_nyq_ = own_an_;
+  b_nyq_ = own_bn_;
+  views_.resize((size_t)num_views);
+  be::stream_sync(stream_);
+}
+
+SlabEngine::~SlabEngine() {
+  try {
+    be::set_device(device_);
+    if (stream_) be::stream_sync(stream_);
+  } catch (...) {
+  }
+  for (size_t v = 0; v < views_.size(); ++v) {
+    be::dfree(views_[v].image);
+    be::dfree(views_[v].weights);
+    for (int i = 0; i < 2; ++i) {
+      be::dfree(views_[v].spec[i]);
+      be::dfree(views_[v].nyq[i]);
+    }
+  }
+  be::dfree(psi_);
+  be::dfree(work_);
+  be::dfree(work_nyq_);
+  be::dfree(own_a_);
+  be::dfree(own_b_);
+  be::dfree(own_an_);
+  be::dfree(own_bn_);
+  if (stream_) be::stream_destroy(stream_);
+}
+
+void SlabEngine::sync() {
+  be::set_device(device_);
+  be::stream_sync(stream_);
+}
+
+void SlabEngine::bind_buffers(float* a_main, float* b_main, float* a_nyq, float* b_nyq) {
+  sync();
+  const bool need_nyq = planA_->nyq_bytes() != 0;
+  if (a_main && b_main && (!need_nyq || (a_nyq && b_nyq))) {
+    a_main_ = a_main;
+    b_main_ = b_main;
+    a_nyq_ = (cfloat*)a_nyq;
+    b_nyq_ = (cfloat*)b_nyq;
+    external_ = true;
+  } else {
+    a_main_ = own_a_;
+    b_main_ = own_b_;
+    a_nyq_ = own_an_;
+    b_nyq_ = own_bn_;
+    external_ = false;
+  }
+}
+
+void SlabEngine::upload_slab(float* dst, const float* host) {
+  const Layout& L = planA_->L;
+  if (L.RP == L.d2)
+    be::h2d(dst, host, L.logical() * sizeof(float), stream_);
+  else
+    be::h2d_2d(dst, (size_t)L.RP * sizeof(float), host, (size_t)L.d2 * sizeof(float),
+               (size_t)L.d2 * sizeof(float), L.rows, stream_);
+}
+
+void SlabEngine::set_psi(const float* host) {
+  be::set_device(device_);
+  if (planA_->L.RP != planA_->L.d2) be::dzero(psi_, planA_->main_bytes(), stream_);
+  upload_slab(psi_, host);
+  be::stream_sync(stream_);
+  work_has_psi_spectrum_ = false;
+}
+
+void SlabEngine::get_psi(float* host) {
+  be::set_device(device_);
+  const Layout& L = planA_->L;
+  be::d2h_2d(host, (size_t)L.d2 * 4, psi_, (size_t)L.RP * 4, (size_t)L.d2 * 4, L.rows, stream_);
+  be::stream_sync(stream_);
+}
+
+void SlabEngine::set_view(int v, const float* image, const float* weights, const float* kernel1,
+                          const int* k1dims, const float* kernel2, const int* k2dims) {
+  if (v < 0 || v >= (int)views_.size()) throw std::out_of_range("mvn: view index");
+  be::set_device(device_);
+  SlabView& s = views_[(size_t)v];
+  const size_t mb = planA_->main_bytes();
+  const size_t nbT = planB_->nyq_bytes();
+  if (!s.image) {
+    s.image = (float*)be::dmalloc(mb);
+    s.weights = (float*)be::dmalloc(mb);
+    for (int i = 0; i < 2; ++i) {
+      s.spec[i] = (float*)be::dmalloc(planB_->main_bytes());
+      if (nbT) s.nyq[i] = (cfloat*)be::dmalloc(nbT);
+    }
+    if (planA_->L.RP != planA_->L.d2) {
+      be::dzero(s.image, mb, stream_);
+      be::dzero(s.weights, mb, stream_);
+    }
+  }
+  upload_slab(s.image, image);
+  upload_slab(s.weights, weights);
+  // PSF spectra: the whole 3-D spectrum is formed locally (three passes on a temporary full
+  // volume) and this rank's dim1 block cut out of it -- position order along dim1 is the same in
+  // the full and in the decomposed transform, so the block is what a decomposed forward
+  // transform of the PSF would leave here.
+  std::shared_ptr<Plan3D> full = PlanStore::get().add(device_, dims_);
+  const Layout& F = full->L;
+  const float scale = (float)(1.0 / (double)F.logical());
+  float* fspec = (float*)be::dmalloc(full->main_bytes());
+  cfloat* fnyq = nullptr;
+  float* dk = nullptr;
+  try {
+    if (full->nyq_bytes()) fnyq = (cfloat*)be::dmalloc(full->nyq_bytes());
+    const float* ks[2] = {kernel1, kernel2};
+    const int* kd[2] = {k1dims, k2dims};
+    const size_t yb = (size_t)(F.d1 / P_);
+    for (int i = 0; i < 2; ++i) {
+      const size_t kb = sizeof(float) * (size_t)kd[i][0] * (size_t)kd[i][1] * (size_t)kd[i][2];
+      dk = (float*)be::dmalloc(kb);
+      be::h2d(dk, ks[i], kb, stream_);
+      full->psf_spectrum(dk, kd[i], scale, fspec, fnyq, stream_);
+      const size_t wrow = yb * (size_t)F.C * sizeof(cfloat);
+      be::d2d_2d(s.spec[i], wrow, (const cfloat*)fspec + (size_t)rank_ * yb * F.C,
+                 (size_t)F.d1 * F.C * sizeof(cfloat), wrow, (size_t)F.d0, stream_);
+      if (fnyq)
+        be::d2d_2d(s.nyq[i], yb * sizeof(cfloat), fnyq + (size_t)rank_ * yb,
+                   (size_t)F.d1 * sizeof(cfloat), yb * sizeof(cfloat), (size_t)F.d0, stream_);
+      be::stream_sync(stream_);
+      be::dfree(dk);
+      dk = nullptr;
+    }
+  } catch (...) {
+    try {
+      be::stream_sync(stream_);
+    } catch (...) {
+    }
+    be::dfree(dk);
+    be::dfree(fspec);
+    be::dfree(fnyq);
+    throw;
+  }
+  be::dfree(fspec);
+  be::dfree(fnyq);
+  s.set = true;
+}
+
+void SlabEngine::begin_sweeps() { work_has_psi_spectrum_ = false; }
+
+// conv 0 starts from psi (its last-axis transform may already sit in the work buffer, left there
+// by the previous view's fused update pass); conv 1 starts from the quotient's last-axis
+// transform, left there by step_unpack(conv 0)
+void SlabEngine::step_pack(int v, int conv) {
+  be::set_device(device_);
+  if (!views_.at((size_t)v).set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
+  const Plan3D& A = *planA_;
+  const Layout& L = A.L;
+  cfloat* W = (cfloat*)work_;
+  if (conv == 0) {
+    if (!work_has_psi_spectrum_) A.rows_r2c(psi_, W, work_nyq_, stream_);
+    work_has_psi_spectrum_ = false;
+  }
+  A.axis1(MVN_ST_FWD, W, work_nyq_, stream_);
+  const size_t yb = (size_t)(L.d1 / P_);
+  const size_t wrow = yb * (size_t)L.C * sizeof(cfloat);
+  const size_t blk = (size_t)L.d0 * yb * L.C;  // cfloats per destination rank
+  for (int j = 0; j < P_; ++j) {
+    be::d2d_2d((cfloat*)a_main_ + (size_t)j * blk, wrow, W + (size_t)j * yb * L.C,
+               (size_t)L.d1 * L.C * sizeof(cfloat), wrow, (size_t)L.d0, stream_);
+    if (work_nyq_)
+      be::d2d_2d(a_nyq_ + (size_t)j * L.d0 * yb, yb * sizeof(cfloat), work_nyq_ + (size_t)j * yb,
+                 (size_t)L.d1 * sizeof(cfloat), yb * sizeof(cfloat), (size_t)L.d0, stream_);
+  }
+}
+
+void SlabEngine::step_mid(int v, int conv) {
+  be::set_device(device_);
+  const SlabView& s = views_.at((size_t)v);
+  planB_->axis0(MVN_ST_FWD_MUL_INV, (cfloat*)b_main_, b_nyq_, (const cfloat*)s.spec[conv],
+                s.nyq[conv], stream_);
+}
+
+void SlabEngine::step_unpack(int v, int conv, double lambda, float min_value, bool feed_next) {
+  be::set_device(device_);
+  const SlabView& s = views_.at((size_t)v);
+  const Plan3D& A = *planA_;
+  const Layout& L = A.L;
+  cfloat* W = (cfloat*)work_;
+  const size_t yb = (size_t)(L.d1 / P_);
+  const size_t wrow = yb * (size_t)L.C * sizeof(cfloat);
+  const size_t blk = (size_t)L.d0 * yb * L.C;
+  for (int j = 0; j < P_; ++j) {
+    be::d2d_2d(W + (size_t)j * yb * L.C, (size_t)L.d1 * L.C * sizeof(cfloat),
+               (const cfloat*)a_main_ + (size_t)j * blk, wrow, wrow, (size_t)L.d0, stream_);
+    if (work_nyq_)
+      be::d2d_2d(work_nyq_ + (size_t)j * yb, (size_t)L.d1 * sizeof(cfloat),
+                 a_nyq_ + (size_t)j * L.d0 * yb, yb * sizeof(cfloat), yb * sizeof(cfloat),
+                 (size_t)L.d0, stream_);
+  }
+  A.axis1(MVN_ST_INV, W, work_nyq_, stream_);
+  EpilogueParams e;
+  std::memset(&e, 0, sizeof(e));
+  e.scale = 1.f;  // 1/N lives in the PSF spectra
+  if (conv == 0) {
+    e.mode = MVN_EPI_DIVIDE;
+    e.view = s.image;
+    if (A.can_fuse_rows()) {
+      A.rows_c2r_r2c(W, work_nyq_, e, stream_);
+    } else {
+      A.rows_c2r(W, work_nyq_, work_, e, stream_);
+      A.rows_r2c(work_, W, work_nyq_, stream_);
+    }
+  } else {
+    e.mode = MVN_EPI_UPDATE;
+    e.psi = psi_;
+    e.weights = s.weights;
+    e.lambda = lambda;
+    e.lambda_inv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
+    e.min_value = min_value;
+    if (A.can_fuse_rows() && feed_next) {
+      A.rows_c2r_r2c(W, work_nyq_, e, stream_);
+      work_has_psi_spectrum_ = true;
+    } else {
+      A.rows_c2r(W, work_nyq_, psi_, e, stream_);
+    }
+  }
+}
+
 }  // namespace mvn

@@ -281,4 +281,79 @@ class Engine {
   Profiler prof_;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Slab-decomposed engine: the reference's SEQUENTIAL sweep over views on several GPUs (SURVEY.md
+// 8e row 3).  Rank r of P keeps planes [r d0/P, (r+1) d0/P) of psi and of every view and weight
+// stack.  Last-axis and dim1 passes are local to a plane; the dim0 pass needs whole lines along
+// d0, so each convolution exchanges the half-transformed slab twice:
+//     W [d0/P][d1][C]  --pack-->  A [P][d0/P][d1/P][C]  ==all-to-all==>  B [d0][d1/P][C]
+//     dim0 FWD * PSF * INV on B (PSF spectra kept in the same transposed layout)
+//     B, seen as [P][d0/P][d1/P][C]  ==all-to-all==>  A  --unpack-->  W
+// The exchanges themselves are the caller's (torch.distributed / RCCL on buffers it binds);
+// everything between them is the single-GPU engine's kernels on two plans, (d0/P, d1, d2) for the
+// plane-local passes and (d0, d1/P, d2) for the dim0 pass, so the arithmetic is the sequential
+// sweep's, pass for pass.  Requires d0 % P == 0, d1 % P == 0, d0/P >= 2, d1/P >= 2.
+// ---------------------------------------------------------------------------------------------
+class SlabEngine {
+ public:
+  SlabEngine(int device, const shape_t& dims, int nranks, int rank, int num_views);
+  ~SlabEngine();
+  SlabEngine(const SlabEngine&) = delete;
+  SlabEngine& operator=(const SlabEngine&) = delete;
+
+  int device() const { return device_; }
+  int nranks() const { return P_; }
+  int rank() const { return rank_; }
+  const Layout& slab_layout() const { return planA_->L; }  // (d0/P, d1, d2)
+  size_t main_floats() const { return planA_->L.real_floats(); }    // per exchange buffer
+  size_t nyq_floats() const { return 2 * planA_->L.nyq_cplx(); }
+
+  // image / weights: this rank's planes, dense [d0/P][d1][d2]; kernels: whole
+  void set_view(int v, const float* image_slab, const float* weights_slab, const float* kernel1,
+                const int* k1dims, const float* kernel2, const int* k2dims);
+  void set_psi(const float* psi_slab);
+  void get_psi(float* psi_slab);
+  // exchange buffers (device memory): A is packed / unpacked here, B is what the dim0 pass
+  // works on.  nullptr arguments return to engine-owned buffers.
+  void bind_buffers(float* a_main, float* b_main, float* a_nyq, float* b_nyq);
+  float* a_main() { return a_main_; }
+  float* b_main() { return b_main_; }
+  float* a_nyq() { return (float*)a_nyq_; }
+  float* b_nyq() { return (float*)b_nyq_; }
+
+  // one view update = for conv in {0, 1}: pack, [A -> B all-to-all], mid, [B -> A all-to-all],
+  // unpack.  All steps are asynchronous on stream(); sync() before handing a buffer to a
+  // collective on another stream.
+  void begin_sweeps();  // psi may have been replaced: forget the cached last-axis spectrum
+  void step_pack(int v, int conv);
+  void step_mid(int v, int conv);
+  void step_unpack(int v, int conv, double lambda, float min_value, bool feed_next);
+  void sync();
+  be::stream_t stream() const { return stream_; }
+
+ private:
+  void upload_slab(float* dst, const float* host);
+  int device_, P_, rank_;
+  shape_t dims_;
+  std::shared_ptr<Plan3D> planA_, planB_;
+  be::stream_t stream_ = nullptr;
+  float* psi_ = nullptr;
+  float* work_ = nullptr;
+  cfloat* work_nyq_ = nullptr;
+  float *a_main_ = nullptr, *b_main_ = nullptr;
+  cfloat *a_nyq_ = nullptr, *b_nyq_ = nullptr;
+  bool external_ = false;
+  float *own_a_ = nullptr, *own_b_ = nullptr;
+  cfloat *own_an_ = nullptr, *own_bn_ = nullptr;
+  bool work_has_psi_spectrum_ = false;
+  struct SlabView {
+    float* image = nullptr;
+    float* weights = nullptr;
+    float* spec[2] = {nullptr, nullptr};   // transposed slabs [d0][d1/P][C]
+    cfloat* nyq[2] = {nullptr, nullptr};   // [d0][d1/P]
+    bool set = false;
+  };
+  std::vector<SlabView> views_;
+};
+
 }  // namespace mvn

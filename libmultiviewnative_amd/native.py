@@ -36,6 +36,9 @@ ENGINE_ABI_SYMBOLS = [
     "mvn_engine_bind_delta", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
     "mvn_engine_profile", "mvn_engine_profile_read", "mvn_kernel_kind_count",
     "mvn_kernel_kind_name", "mvn_engine_B",
+    "mvn_slab_create", "mvn_slab_destroy", "mvn_slab_set_view", "mvn_slab_set_psi", "mvn_slab_get_psi",
+    "mvn_slab_buffer_sizes", "mvn_slab_buffers", "mvn_slab_bind_buffers", "mvn_slab_begin",
+    "mvn_slab_pack", "mvn_slab_mid", "mvn_slab_unpack", "mvn_slab_sync", "mvn_slab_stream",
 ]
 
 
@@ -111,6 +114,21 @@ class Binding:
         l.mvn_engine_profile.argtypes = [C.c_void_p, C.c_int]
         l.mvn_engine_profile_read.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                               C.POINTER(C.c_long)]
+        vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+        l.mvn_slab_create.argtypes = [C.c_int, i3, C.c_int, C.c_int, C.c_int, vpp]
+        l.mvn_slab_destroy.argtypes = [vp]
+        l.mvn_slab_set_view.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_float_p, i3, c_float_p, i3]
+        l.mvn_slab_set_psi.argtypes = [vp, c_float_p]
+        l.mvn_slab_get_psi.argtypes = [vp, c_float_p]
+        l.mvn_slab_buffer_sizes.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        l.mvn_slab_buffers.argtypes = [vp, vpp, vpp, vpp, vpp]
+        l.mvn_slab_bind_buffers.argtypes = [vp, vp, vp, vp, vp]
+        l.mvn_slab_begin.argtypes = [vp]
+        l.mvn_slab_pack.argtypes = [vp, C.c_int, C.c_int]
+        l.mvn_slab_mid.argtypes = [vp, C.c_int, C.c_int]
+        l.mvn_slab_unpack.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_float, C.c_int]
+        l.mvn_slab_sync.argtypes = [vp]
+        l.mvn_slab_stream.argtypes = [vp, vpp]
         l.mvn_engine_B.argtypes = [C.c_void_p]
         l.mvn_engine_B.restype = C.c_size_t
 
@@ -224,6 +242,9 @@ class Binding:
     def engine(self, shape, num_views, device=0):
         return EngineHandle(self, shape, num_views, device)
 
+    def slab_engine(self, shape, nranks, rank, num_views, device=0):
+        return SlabHandle(self, shape, nranks, rank, num_views, device)
+
 
 class EngineHandle:
     """Resident RL engine (``mvn_engine_*``)."""
@@ -328,3 +349,75 @@ def lib():
     if _product is None:
         _product = Binding(PRODUCT_SO)
     return _product
+
+
+class SlabHandle:
+    """Slab-decomposed RL engine (``mvn_slab_*``): this rank's planes of a volume of `shape`."""
+
+    def __init__(self, binding, shape, nranks, rank, num_views, device=0):
+        self.b = binding
+        self.shape = tuple(int(s) for s in shape)
+        self.nranks, self.rank, self.num_views = nranks, rank, num_views
+        self.slab_shape = (self.shape[0] // nranks, self.shape[1], self.shape[2])
+        h = C.c_void_p()
+        binding.check(binding.l.mvn_slab_create(device, _dims(self.shape), nranks, rank, num_views,
+                                                C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.b.l.mvn_slab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _slab(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.shape != self.slab_shape:
+            raise ValueError("expected this rank's slab %r, got %r" % (self.slab_shape, a.shape))
+        return a
+
+    def set_view(self, v, image_slab, weights_slab, kernel1, kernel2):
+        im, w = self._slab(image_slab), self._slab(weights_slab)
+        k1 = np.ascontiguousarray(kernel1, dtype=np.float32)
+        k2 = np.ascontiguousarray(kernel2, dtype=np.float32)
+        self.b.check(self.b.l.mvn_slab_set_view(self.h, v, fptr(im), fptr(w), fptr(k1), _dims(k1.shape),
+                                                fptr(k2), _dims(k2.shape)))
+
+    def set_psi(self, psi_slab):
+        self.b.check(self.b.l.mvn_slab_set_psi(self.h, fptr(self._slab(psi_slab))))
+        self.b.check(self.b.l.mvn_slab_begin(self.h))
+
+    def get_psi(self):
+        out = np.empty(self.slab_shape, np.float32)
+        self.b.check(self.b.l.mvn_slab_get_psi(self.h, fptr(out)))
+        return out
+
+    def buffer_sizes(self):
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self.b.check(self.b.l.mvn_slab_buffer_sizes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def buffers(self):
+        p = [C.c_void_p() for _ in range(4)]
+        self.b.check(self.b.l.mvn_slab_buffers(self.h, *[C.byref(x) for x in p]))
+        return [x.value for x in p]
+
+    def bind_buffers(self, a_main, b_main, a_nyq, b_nyq):
+        self.b.check(self.b.l.mvn_slab_bind_buffers(self.h, a_main, b_main, a_nyq, b_nyq))
+
+    def pack(self, v, conv):
+        self.b.check(self.b.l.mvn_slab_pack(self.h, v, conv))
+
+    def mid(self, v, conv):
+        self.b.check(self.b.l.mvn_slab_mid(self.h, v, conv))
+
+    def unpack(self, v, conv, lambda_, min_value, feed_next):
+        self.b.check(self.b.l.mvn_slab_unpack(self.h, v, conv, lambda_, min_value, 1 if feed_next else 0))
+
+    def sync(self):
+        self.b.check(self.b.l.mvn_slab_sync(self.h))

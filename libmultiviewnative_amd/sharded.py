@@ -47,3 +47,43 @@ class SimultaneousDriver:
         for _ in range(iterations):
             self.step(lambda_, min_value)
         self.engine.sync()
+
+
+class SlabDriver:
+    """The reference's sequential view-after-view sweep on several GPUs, volume split in slabs of
+    planes: exact single-GPU arithmetic, four all-to-all exchanges per
+    (view, iteration).
+
+    `engine` is a ``native.SlabHandle`` (or anything with pack / mid / unpack / sync);
+    `a_main, b_main, a_nyq, b_nyq` are torch tensors aliasing its exchange buffers (``a_nyq`` /
+    ``b_nyq`` may be None for odd d2); `dist` is ``torch.distributed``.
+    """
+
+    def __init__(self, engine, a_main, b_main, a_nyq, b_nyq, dist, after_collective=None):
+        self.engine = engine
+        self.a_main, self.b_main, self.a_nyq, self.b_nyq = a_main, b_main, a_nyq, b_nyq
+        self.dist = dist
+        self.after_collective = after_collective
+
+    def _exchange(self, src_main, dst_main, src_nyq, dst_nyq):
+        self.engine.sync()  # the buffers must be complete before the collective reads them
+        self.dist.all_to_all_single(dst_main, src_main)
+        if src_nyq is not None:
+            self.dist.all_to_all_single(dst_nyq, src_nyq)
+        if self.after_collective is not None:
+            self.after_collective()
+
+    def view_update(self, v, lambda_, min_value, feed_next):
+        for conv in (0, 1):
+            self.engine.pack(v, conv)
+            self._exchange(self.a_main, self.b_main, self.a_nyq, self.b_nyq)
+            self.engine.mid(v, conv)
+            self._exchange(self.b_main, self.a_main, self.b_nyq, self.a_nyq)
+            self.engine.unpack(v, conv, lambda_, min_value, feed_next)
+
+    def run(self, iterations, num_views, lambda_, min_value):
+        for it in range(iterations):
+            for v in range(num_views):
+                last = it == iterations - 1 and v == num_views - 1
+                self.view_update(v, lambda_, min_value, not last)
+        self.engine.sync()

@@ -699,3 +699,52 @@ def test_batched_forward_matches_single_and_numpy(gpu):
             ref = np.fft.rfftn(stacks[b].astype(np.float64))
             assert np.abs(many[b] - ref).max() <= 2e-5 * np.abs(ref).max()
     assert gpu.fft3_many_time((8, 8, 8), 2, 0, 1) >= 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,V", [((64, 64, 128), 2), ((12, 10, 9), 2), ((128, 256, 64), 1)])
+def test_slab_engine_one_rank_equals_resident_engine(gpu, shape, V):
+    # with one rank the two all-to-all exchanges are plain copies A -> B and
+    # B -> A; pack / dim0 pass / unpack must then reproduce the resident engine's sweep
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    D2D = 3
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (5, 5, 5), seed=4)
+    se = gpu.slab_engine(shape, 1, 0, V)
+    for v in range(V):
+        se.set_view(v, views[v], w[v], k1[v], k2[v])
+    se.set_psi(psi0)
+    a, b, an, bn = se.buffers()
+    nm, nn = se.buffer_sizes()
+
+    def copy(dst, src, n):
+        if n:
+            assert hip.hipMemcpy(dst, src, n * 4, D2D) == 0
+
+    its = 2
+    for it in range(its):
+        for v in range(V):
+            for conv in (0, 1):
+                se.pack(v, conv)
+                se.sync()
+                copy(b, a, nm)
+                copy(bn, an, nn)
+                se.mid(v, conv)
+                se.sync()
+                copy(a, b, nm)
+                copy(an, bn, nn)
+                se.unpack(v, conv, 0.006, 1e-4, not (it == its - 1 and v == V - 1))
+    se.sync()
+    got = se.get_psi()
+    se.close()
+    e = gpu.engine(shape, V)
+    for v in range(V):
+        e.set_view(v, views[v], w[v], k1[v], k2[v])
+    e.set_psi(psi0)
+    e.iterate(its, 0.006, 1e-4)
+    e.sync()
+    ref = e.get_psi()
+    e.close()
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()

@@ -601,10 +601,11 @@ MVN_HD void fx_strided_body(const StridedParams& P, long first, long total, long
 // ---------------------------------------------------------------------------------------------
 // LDS-staged variant of the fused FWD * PSF * INV pass, used where two or more workgroups share
 // a CU (tiles of at most half the LDS).  Every stage goes through the LDS with one column per work
-// item (fx_stage), which keeps the working set at ~50 registers; that leaves room to hold this
-// tile's PSF operands AND the next tile's rows in registers at 4 waves per SIMD -- the
-// register-staged body above spills when it tries (measured: 0.38 ms vs 0.35 ms at 512^3, and
-// 5.4 ms vs 3.0 ms on the 320-long axis of 320 x 1920 x 1920).
+// item (fx_stage), which keeps the working set at ~50 registers next to the tile's PSF operands.
+// The register-staged walking body above cannot hold next tile + PSF tile + working tile in the
+// 128 registers that two workgroups per CU leave and spills (measured: 0.38 ms vs 0.33 ms at
+// 512^3, and 5.4 ms vs 3.0 ms on the 320-long axis of 320 x 1920 x 1920); walking itself did not
+// pay for this body either (0.38 ms vs 0.33 ms one workgroup per tile).
 // ---------------------------------------------------------------------------------------------
 template <int N>
 struct FxFusedCfg {
@@ -625,8 +626,7 @@ struct FxFusedCfg {
 
 template <int N>
 struct FxFusedRegs {
-  qfloat v[FxFusedCfg<N>::U];  // tile rows, fetched one tile ahead
-  qfloat g[FxFusedCfg<N>::U];  // PSF-spectrum operands of the current tile
+  qfloat g[FxFusedCfg<N>::U];  // PSF-spectrum operands of the tile
 };
 
 // thread <-> 16-byte chunk q of rows jr + u RPT
@@ -640,19 +640,21 @@ MVN_HD void fx_fu_fetch(const cfloat* from, const StridedParams& P, long base, q
   for (int u = 0; u < C::U; ++u) dst[u] = *reinterpret_cast<const qfloat*>(src + u * rstep);
 }
 
-// tile entry: request this tile's PSF operands (the spectrum is stored in the digit-reversed row
-// order the forward transform produces, i.e. row for row what the LDS holds after it), put the
-// rows fetched ahead into the LDS, request the next tile's rows
+// tile entry: this tile's rows and its PSF operands (the spectrum is stored in the digit-reversed
+// row order the forward transform produces, i.e. row for row what the LDS holds after it) are
+// requested together; the rows go to the LDS, the operands stay in registers until the multiply
 template <int N>
-MVN_HD void fx_fu_top(const StridedParams& P, long base, long next_base, bool has_next, cfloat* buf,
+MVN_HD void fx_fu_top(const StridedParams& P, long base, cfloat* buf, cfloat* tws,
                       FxFusedRegs<N>& r, int tid) {
   typedef FxFusedCfg<N> C;
+  qfloat v[C::U];
+  fx_fu_fetch<N>(P.src ? P.src : P.data, P, base, v, tid);
   fx_fu_fetch<N>(P.spec, P, base, r.g, tid);
+  fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
   const int q = tid % C::CH, jr = tid / C::CH;
 #pragma unroll
   for (int u = 0; u < C::U; ++u)
-    *reinterpret_cast<qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q) = r.v[u];
-  if (has_next) fx_fu_fetch<N>(P.src ? P.src : P.data, P, next_base, r.v, tid);
+    *reinterpret_cast<qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q) = v[u];
 }
 
 template <int N>
@@ -678,28 +680,20 @@ MVN_HD void fx_fu_store(const StridedParams& P, long base, const cfloat* buf, in
         *reinterpret_cast<const qfloat*>(buf + (jr + u * C::RPT) * C::TP + 2 * q);
 }
 
+// one tile per workgroup (see mvn_kernels.hip: walking was slower for this body)
 template <int N, typename Ctx>
-MVN_HD void fx_fused_lds_body(const StridedParams& P, long first, long total, long step,
-                              cfloat* lds, Ctx& ctx) {
+MVN_HD void fx_fused_lds_body(const StridedParams& P, long block, cfloat* lds, Ctx& ctx) {
   typedef FxFusedCfg<N> C;
   constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
   (void)NT_;
   cfloat* buf = lds;
   cfloat* tws = lds + N * TP;
-  if (first >= total) return;
-  // the table is first read after the barrier that ends the tile-entry phase
-  MVN_PHASE_NOSYNC(ctx, (fx_fu_fetch<N>(P.src ? P.src : P.data, P, fx_st_base<N>(P, first), r.v, tid),
-                         fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(N), tid)));
-  for (long block = first; block < total; block += step) {
-    const long base = fx_st_base<N>(P, block);
-    const bool has_next = block + step < total;
-    const long next_base = has_next ? fx_st_base<N>(P, block + step) : base;
-    MVN_PHASE(ctx, (fx_fu_top<N>(P, base, next_base, has_next, buf, r, tid)));
-    fx_dif<N, T, TP, false, NT, -1>(buf, tws, ctx);
-    MVN_PHASE(ctx, (fx_fu_mul<N>(buf, r, tid)));
-    fx_dit<N, T, TP, false, NT, +1>(buf, tws, ctx);
-    MVN_PHASE(ctx, (fx_fu_store<N>(P, base, buf, tid)));
-  }
+  const long base = fx_st_base<N>(P, block);
+  MVN_PHASE(ctx, (fx_fu_top<N>(P, base, buf, tws, r, tid)));
+  fx_dif<N, T, TP, false, NT, -1>(buf, tws, ctx);
+  MVN_PHASE(ctx, (fx_fu_mul<N>(buf, r, tid)));
+  fx_dit<N, T, TP, false, NT, +1>(buf, tws, ctx);
+  MVN_PHASE(ctx, (fx_fu_store<N>(P, base, buf, tid)));
 }
 
 // which body, register block and workgroup size a (length, mode) pair uses
@@ -712,9 +706,10 @@ struct FxStridedSel {
   typedef FxCtx<Regs, NT> Ctx;
   static MVN_HD void run(const StridedParams& P, long first, long total, long step, cfloat* lds,
                          Ctx& ctx) {
-    if constexpr (LDS_FUSED)
-      fx_fused_lds_body<N>(P, first, total, step, lds, ctx);
-    else
+    if constexpr (LDS_FUSED) {
+      // launched one workgroup per tile (step == grid size == total)
+      for (long block = first; block < total; block += step) fx_fused_lds_body<N>(P, block, lds, ctx);
+    } else
       fx_strided_body<N, MODE>(P, first, total, step, lds, ctx);
   }
 };

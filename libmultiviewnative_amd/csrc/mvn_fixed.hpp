@@ -729,7 +729,10 @@ struct FxStridedSel {
 template <int H>
 struct FxRowsCfg {
   static constexpr bool PAD = fx_pow2(H);  // the spare-row trick relies on power-of-two block sizes
-  static constexpr int T = H <= 512 ? 16 : 8;
+#ifndef MVN_FX_ROWS_T
+#define MVN_FX_ROWS_T 16
+#endif
+  static constexpr int T = H > 512 ? 8 : ((fx_pow2(H) && H >= 128) ? MVN_FX_ROWS_T : 16);
   static constexpr int TP = T + 1;
   static constexpr int QR = H / 2;  // 16-byte chunks per spectral row (2 complex bins each)
   static constexpr int R0 = fx_radix(H, 0);

@@ -53,6 +53,15 @@ void event_record(event_t e, stream_t s);
 void event_sync(event_t e);
 float event_elapsed_ms(event_t a, event_t b);
 
+// stream capture into an executable graph (launch-bound small volumes replay a whole sweep with
+// one submission); the host emulation has none
+typedef void* graph_exec_t;
+bool graphs_supported();
+void capture_begin(stream_t s);
+graph_exec_t capture_end(stream_t s);  // ends the capture and instantiates the graph
+void graph_launch(graph_exec_t g, stream_t s);
+void graph_destroy(graph_exec_t g);
+
 // ---- kernel launches --------------------------------------------------------------------
 void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int nthreads, size_t lds_bytes,
                      stream_t s);

@@ -94,6 +94,12 @@ float event_elapsed_ms(event_t a, event_t b) {
   return std::chrono::duration<float, std::milli>(((EmuEvent*)b)->t - ((EmuEvent*)a)->t).count();
 }
 
+bool graphs_supported() { return false; }
+void capture_begin(stream_t) { throw std::runtime_error("mvn: no graphs in the host emulation"); }
+graph_exec_t capture_end(stream_t) { throw std::runtime_error("mvn: no graphs in the host emulation"); }
+void graph_launch(graph_exec_t, stream_t) { throw std::runtime_error("mvn: no graphs in the host emulation"); }
+void graph_destroy(graph_exec_t) {}
+
 // fixed-length kernels: every phase is run for all thread ids in turn (real thread mapping)
 template <int H>
 static void emu_rows_fused(const RowsParams& p, long ntiles) {

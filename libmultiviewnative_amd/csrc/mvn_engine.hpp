@@ -274,9 +274,15 @@ class Engine {
   // simultaneous mode: psi after the forward last-axis and dim1 passes, shared by all local views
   float* psi_spec_ = nullptr;
   cfloat* psi_spec_nyq_ = nullptr;
-  bool work_has_psi_spectrum_ = false;
+  bool work_has_psi_spectrum_ = false;  // work_ holds the last-axis transform of the current psi
   bool quotient_guard_ = false;
-  long pair_counter_ = 0;  // work_ holds the last-axis transform of the current psi
+  long pair_counter_ = 0;
+  // one steady-state sweep over all views captured as a graph (small, launch-bound volumes);
+  // valid for the parameters it was captured with, buffers never move during an engine's life
+  be::graph_exec_t sweep_graph_ = nullptr;
+  double graph_lambda_ = 0;
+  float graph_min_ = 0;
+  bool graph_guard_ = false;
   std::vector<ViewSlot> views_;
   Profiler prof_;
 };

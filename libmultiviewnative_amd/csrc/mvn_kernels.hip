@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <stdexcept>
 #include <string>
 
@@ -280,13 +283,42 @@ float event_elapsed_ms(event_t a, event_t b) {
   return ms;
 }
 
+bool graphs_supported() { return true; }
+void capture_begin(stream_t s) {
+  // thread-local mode: the staging thread of the ABI call may allocate / free meanwhile
+  HIP_CHECK(hipStreamBeginCapture(hs(s), hipStreamCaptureModeThreadLocal));
+}
+graph_exec_t capture_end(stream_t s) {
+  hipGraph_t g = nullptr;
+  HIP_CHECK(hipStreamEndCapture(hs(s), &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  HIP_CHECK(err);
+  return (graph_exec_t)e;
+}
+void graph_launch(graph_exec_t g, stream_t s) { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)g, hs(s))); }
+void graph_destroy(graph_exec_t g) {
+  if (g) (void)hipGraphExecDestroy((hipGraphExec_t)g);
+}
+
 // a workgroup may ask for up to the CU's whole 160 KiB of LDS; above the 64 KiB default the
 // kernel needs the attribute raised once
 template <typename K>
 static void ensure_lds(K kernel, size_t lds_bytes) {
-  if (lds_bytes > 64 * 1024)
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  if (lds_bytes <= 64 * 1024) return;
+  // once per (kernel, size): the attribute call costs a few microseconds per launch otherwise
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> done;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  const auto key = std::make_pair(fn, dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find(key);
+  if (it != done.end() && it->second >= lds_bytes) return;
+  HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  done[key] = lds_bytes;
 }
 
 static void check_launch(long nblocks, int nthreads, size_t lds_bytes) {
@@ -320,6 +352,21 @@ static int device_cu_count() {
   return cus;
 }
 
+// resident workgroups per CU of a (kernel, block size, LDS) triple: asked once, not per launch
+static int resident_per_cu(const void* kernel, int nthreads, size_t lds_bytes) {
+  static std::mutex mu;
+  static std::map<std::tuple<const void*, int, size_t>, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_tuple(kernel, nthreads, lds_bytes);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nthreads, lds_bytes));
+  if (per_cu < 1) per_cu = 1;
+  cache[key] = per_cu;
+  return per_cu;
+}
+
 template <typename K>
 static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads, size_t lds_bytes,
                            stream_t s, bool walk) {
@@ -330,10 +377,8 @@ static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads
   }();
   long grid = nblocks;
   if (mode > 0 && walk) {
-    int per_cu = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nthreads, lds_bytes));
-    if (per_cu < 1) per_cu = 1;
-    const long resident = (long)per_cu * device_cu_count() * mode;
+    const long resident = (long)resident_per_cu(reinterpret_cast<const void*>(kernel), nthreads, lds_bytes) *
+                          device_cu_count() * mode;
     if (grid > resident) grid = resident;
   }
   p.nblocks = nblocks;

@@ -1,5 +1,7 @@
 """Parity of the HIP hot path (through the C-ABI of lib/libmultiviewnative.so) against the CPU
 oracle, the committed golden values and size-independent properties.  Needs a real MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -748,3 +750,51 @@ def test_slab_engine_one_rank_equals_resident_engine(gpu, shape, V):
     e.close()
     assert np.all(np.isfinite(got))
     assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+_GRAPH_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from libmultiviewnative_amd import native
+from ref_fixtures import realistic_views
+shape = tuple(int(x) for x in sys.argv[3:6]); V, its = 3, 6
+_, views, k1, k2, w, psi0 = realistic_views(shape, V, (5, 5, 5), seed=12)
+lib = native.lib()
+e = lib.engine(shape, V)
+for v in range(V):
+    e.set_view(v, views[v], w[v], k1[v], k2[v])
+out = []
+for lam in (0.006, 0.0, 0.0):      # second and third: re-capture on a parameter change, then re-use
+    e.set_psi(psi0); e.iterate(its, lam, 1e-4); e.sync(); out.append(e.get_psi())
+e.close()
+np.save(sys.argv[2], np.stack(out))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(32, 32, 32), (64, 64, 128), (24, 20, 18)])
+def test_graph_replayed_sweeps_equal_direct_launches(gpu, shape, tmp_path):
+    # MVN_GRAPH=1 (opt-in): sweeps 2..n-1 of a call are replayed from a captured graph on small
+    # volumes (Engine::iterate).  A child process runs with it, this process with direct launches;
+    # same kernels in the same order, so the results must be bit-identical.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "graph.npy")
+    env = dict(os.environ, MVN_GRAPH="1")
+    subprocess.run([sys.executable, "-c", _GRAPH_CHILD, root, out] + [str(x) for x in shape],
+                   check=True, env=env, timeout=300)
+    got = np.load(out)
+    V, its = 3, 6
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (5, 5, 5), seed=12)
+    e = gpu.engine(shape, V)
+    for v in range(V):
+        e.set_view(v, views[v], w[v], k1[v], k2[v])
+    for i, lam in enumerate((0.006, 0.0, 0.0)):
+        e.set_psi(psi0)
+        e.iterate(its, lam, 1e-4)
+        e.sync()
+        ref = e.get_psi()
+        assert np.all(np.isfinite(ref))
+        assert np.array_equal(got[i], ref)
+    e.close()

@@ -1,4 +1,5 @@
-// mvn_fixed.hpp -- compile-time specialised pass bodies for power-of-two line lengths.
+// mvn_fixed.hpp -- compile-time specialised pass bodies for the line lengths 2^a 3^b 5^c 7^d listed
+// in mvn_fixed_geom.hpp (powers of two 64..1024 / 2048 and the common mixed-radix sizes).
 //
 // The generic bodies of mvn_pass_bodies.hpp take the radix schedule at run time; PMC counters on
 // MI355X showed them VALU-bound (index arithmetic, multiply-high divisions, per-element address

@@ -9,6 +9,10 @@
 //   k_strided<MODE>           c2c passes along dim1 / dim0 on tiles of neighbouring columns;
 //                             MODE FWD_MUL_INV fuses forward dim0, the PSF-spectrum multiply
 //                             (multiply_scaled, inc/cuda_kernels.cuh:213-242) and inverse dim0
+//   kx_rows_* / kx_strided    the same passes with every length, radix and tile shape a
+//                             template constant (mvn_fixed.hpp); kx_rows_c2r_r2c additionally
+//                             fuses c2r + pointwise step + r2c of the next convolution; the
+//                             strided ones walk over several tiles per workgroup
 //   k_scatter_psf             device-side wrapped insert (fftShiftKernel,
 //                             src/multiviewnative.cu:154-192)
 //   k_divide / k_update / k_update_legacy_tikhonov / k_axpy1   stand-alone pointwise ops for the
@@ -87,17 +91,10 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams
   fx_rows_c2r_body<H, EPI>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
-// The divide form needs 93 VGPRs unconstrained - just above the 84 that let three 512-thread
-// workgroups share a CU; asking for 6 waves per SIMD makes the allocator fit.
-#ifndef MVN_ROWS_DIV_WAVES
-#define MVN_ROWS_DIV_WAVES 1
-#endif
-constexpr int fx_rows_fused_waves(int nt, int epi) {
-  return (epi == MVN_EPI_DIVIDE && nt == 512) ? MVN_ROWS_DIV_WAVES : 1;
-}
+// (The divide form needs 93 VGPRs, just above the 84 that would let three 512-thread workgroups
+// share a CU; forcing it there with a waves-per-SIMD bound spilled 56 bytes and gained nothing.)
 template <int H, int EPI>
-__global__ void __launch_bounds__(FxRowsCfg<H>::NT, fx_rows_fused_waves(FxRowsCfg<H>::NT, EPI))
-    kx_rows_c2r_r2c(const RowsParams p) {
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;

@@ -1011,7 +1011,11 @@ void SlabEngine::sync() {
 void SlabEngine::bind_buffers(float* a_main, float* b_main, float* a_nyq, float* b_nyq) {
   sync();
   const bool need_nyq = planA_->nyq_bytes() != 0;
-  if (a_main && b_main && (!need_nyq || (a_nyq && b_nyq))) {
+  const bool any = a_main || b_main || a_nyq || b_nyq;
+  const bool all = a_main && b_main && (!need_nyq || (a_nyq && b_nyq));
+  if (any && !all)
+    throw std::invalid_argument("mvn: bind all exchange buffers (main and, for even d2, Nyquist) or none");
+  if (all) {
     a_main_ = a_main;
     b_main_ = b_main;
     a_nyq_ = (cfloat*)a_nyq;

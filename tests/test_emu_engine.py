@@ -440,3 +440,78 @@ def test_psf_spectra_reused_across_calls(emu):
     h3, m3 = emu.psf_cache_counters()
     assert (h3 - h2, m3 - m2) == (3, 1)
     emu.l.mvn_release_cached_engines()
+
+
+def _slab_ranks_in_one_process(emu, shape, V, P, its=2):
+    """P slab engines in this process; the all-to-all exchanges are done by hand on their
+    (host-emulation) buffers: block j of rank i's send buffer -> block i of rank j's receive buffer."""
+    import ctypes as C
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (3, 3, 3), seed=31)
+    zs = [r * shape[0] // P for r in range(P + 1)]
+    engs = [emu.slab_engine(shape, P, r, V) for r in range(P)]
+    for r, e in enumerate(engs):
+        for v in range(V):
+            e.set_view(v, views[v][zs[r]:zs[r + 1]], w[v][zs[r]:zs[r + 1]], k1[v], k2[v])
+        e.set_psi(psi0[zs[r]:zs[r + 1]])
+    nm, nn = engs[0].buffer_sizes()
+
+    def arr(ptr, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n,)) if n else None
+
+    bufs = []
+    for e in engs:
+        a, b, an, bn = e.buffers()
+        bufs.append((arr(a, nm), arr(b, nm), arr(an, nn), arr(bn, nn)))
+
+    def exchange(src, dst):  # src/dst: index of the buffer in the tuple (0 = A, 1 = B)
+        for off, n in ((0, nm), (2, nn)):
+            if not n:
+                continue
+            blk = n // P
+            for i in range(P):
+                for j in range(P):
+                    bufs[j][dst + off][i * blk:(i + 1) * blk] = bufs[i][src + off][j * blk:(j + 1) * blk]
+
+    for it in range(its):
+        for v in range(V):
+            last = it == its - 1 and v == V - 1
+            for conv in (0, 1):
+                for e in engs:
+                    e.pack(v, conv)
+                exchange(0, 1)
+                for e in engs:
+                    e.mid(v, conv)
+                exchange(1, 0)
+                for e in engs:
+                    e.unpack(v, conv, 0.006, 1e-4, not last)
+    got = np.concatenate([e.get_psi() for e in engs], axis=0)
+    for e in engs:
+        e.close()
+    one = emu.engine(shape, V)
+    for v in range(V):
+        one.set_view(v, views[v], w[v], k1[v], k2[v])
+    one.set_psi(psi0)
+    one.iterate(its, 0.006, 1e-4)
+    one.sync()
+    ref = one.get_psi()
+    one.close()
+    return got, ref
+
+
+@pytest.mark.parametrize("shape,V,P", [((8, 12, 16), 2, 2), ((12, 9, 10), 2, 3), ((16, 16, 9), 1, 4),
+                                       ((64, 64, 32), 1, 2)])
+def test_slab_engines_exchanging_by_hand_equal_the_resident_engine(emu, shape, V, P):
+    got, ref = _slab_ranks_in_one_process(emu, shape, V, P)
+    assert got.shape == ref.shape and np.all(np.isfinite(got))
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+def test_slab_engine_rejects_bad_decompositions(emu, capfd):
+    for shape, P in (((9, 12, 16), 2), ((8, 9, 16), 2), ((4, 12, 16), 4)):
+        with pytest.raises(native.MvnError):
+            emu.slab_engine(shape, P, 0, 1)
+    e = emu.slab_engine((8, 12, 16), 2, 1, 1)
+    with pytest.raises(native.MvnError):
+        e.bind_buffers(e.buffers()[0], None, None, None)  # partial binding
+    e.close()
+    capfd.readouterr()

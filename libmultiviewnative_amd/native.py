@@ -17,7 +17,7 @@ from .abi import Workspace, c_float_p, c_int_p, fptr, iptr
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 PRODUCT_SO = os.path.join(LIB_DIR, "libmultiviewnative.so")
-EMU_SO = os.path.join(LIB_DIR, "libmvn_emu.so")
+EMU_SO = os.environ.get("MVN_EMU_SO") or os.path.join(LIB_DIR, "libmvn_emu.so")  # override: sanitizer build
 
 REFERENCE_ABI_SYMBOLS = [
     "inplace_gpu_deconvolve", "inplace_gpu_convolution", "convolution3DfftCUDAInPlace",

@@ -30,6 +30,9 @@ MVN_API int mvn_release_cached_engines(void);
  * MVN_PSF_CACHE=0 disables it.  out[0] = spectra re-used, out[1] = spectra prepared, both since
  * process start. */
 MVN_API int mvn_psf_cache_counters(long out[2]);
+/* passes launched through the long-line (16-column, split-window) kernels since process start
+ * (test / diagnostics; MVN_NO_SPLIT=1 keeps the 8-column kernels) */
+MVN_API long mvn_split_launch_count(void);
 
 /* ---- plan_store (inc/plan_store.cuh: get()/add/has_key/empty/size/clear) ---------------- */
 MVN_API int mvn_plan_store_add(int device, const int dims[3]);

@@ -611,6 +611,8 @@ int mvn_release_cached_engines(void) {
   });
 }
 
+long mvn_split_launch_count(void) { return be::split_launch_count(); }
+
 int mvn_psf_cache_counters(long out[2]) {
   return guarded("mvn_psf_cache_counters", [&] {
     if (!out) throw std::invalid_argument("null out");

@@ -72,6 +72,8 @@ void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int nthreads, 
 // compile-time specialised kernel
 void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int nthreads, size_t lds_bytes,
                          stream_t s);
+// launches that went through the long-line (split-window, 16-column) kernels since process start
+long split_launch_count();
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
                     size_t lds_bytes, stream_t s);
 

@@ -9,6 +9,7 @@
 #error "mvn_backend_emu.cpp is only for the MVN_HOST_EMU test build"
 #endif
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -183,8 +184,48 @@ static void emu_strided_fixed_mode(const StridedParams& p0, long nblocks) {
   }
 }
 
+static std::atomic<long> g_split_launches{0};
+long split_launch_count() { return g_split_launches.load(); }
+
+template <int N>
+static bool emu_try_split(int mode, const StridedParams& p, long nblocks) {
+  if constexpr (FxSplitCfg<N>::USE) {
+    typedef FxSplitCfg<N> C;
+    const char* e = std::getenv("MVN_NO_SPLIT");
+    if ((e && *e && std::strcmp(e, "0") != 0) || mode == MVN_ST_FWD_MUL_INV || p.cstride != 1 ||
+        p.ncols % C::T != 0 || p.tiles_per_outer < 1)
+      return false;
+    StridedParams q = p;
+    const long outer = nblocks / p.tiles_per_outer;
+    q.tiles_per_outer = p.ncols / C::T;
+    q.T = q.TP = C::T;
+    const long nb = outer * q.tiles_per_outer;
+    q.nblocks = nb;
+    ++g_split_launches;
+    const long grid = nb > 1 ? (nb + 1) / 2 : 1;
+    typedef FxCtx<FxSplitRegs<N>, C::NT> Ctx;
+#pragma omp parallel
+    {
+      std::vector<char> lds(sizeof(cfloat) * C::lds_cfloats + 64);
+      std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+      for (long b = 0; b < grid; ++b) {
+        if (mode == MVN_ST_FWD)
+          fx_strided_split_body<N, MVN_ST_FWD>(q, b, nb, grid, (cfloat*)lds.data(), *ctx);
+        else
+          fx_strided_split_body<N, MVN_ST_INV>(q, b, nb, grid, (cfloat*)lds.data(), *ctx);
+      }
+    }
+    return true;
+  } else {
+    (void)mode; (void)p; (void)nblocks;
+    return false;
+  }
+}
+
 template <int N>
 static void emu_strided_fixed(int mode, const StridedParams& p, long nblocks) {
+  if (emu_try_split<N>(mode, p, nblocks)) return;
   if (mode == MVN_ST_FWD) emu_strided_fixed_mode<N, MVN_ST_FWD>(p, nblocks);
   if (mode == MVN_ST_INV) emu_strided_fixed_mode<N, MVN_ST_INV>(p, nblocks);
   if (mode == MVN_ST_FWD_MUL_INV) emu_strided_fixed_mode<N, MVN_ST_FWD_MUL_INV>(p, nblocks);

@@ -62,12 +62,27 @@ struct FxCtx {
     (void)r;                       \
     __VA_ARGS__;                   \
   }
+// At the top of a tile loop: makes the thread id opaque to the optimiser, so that the per-thread
+// address arithmetic of every phase is redone per tile (a handful of integer instructions)
+// instead of being hoisted out of the loop and parked in registers for its whole length.
+#define MVN_TILE_LOOP_TOP(ctx) asm volatile("" : "+v"((ctx).tid))
+// Between independent work items of one thread: stops the scheduler from interleaving them all for
+// ILP, which multiplies the temporaries of a butterfly by the item count (and spills).
+#define MVN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Keeps a walking element offset opaque so that its successors are computed one add at a time,
+// right before use, instead of all up front (40 64-bit addresses are 80 registers).  Applied to an
+// integer, not to the pointer: an opaque pointer loses its address space (flat instead of global
+// loads).
+#define MVN_JIT_ADDRESS(p) asm volatile("" : "+v"(p))
 #else
 template <typename Regs, int NT>
 struct FxCtx {
   Regs regs[NT];
 };
 #define MVN_PHASE_NOSYNC(ctx, ...) MVN_PHASE(ctx, __VA_ARGS__)
+#define MVN_JIT_ADDRESS(p) (void)0
+#define MVN_TILE_LOOP_TOP(ctx) (void)0
+#define MVN_SCHED_FENCE() (void)0
 #define MVN_PHASE(ctx, ...)                  \
   for (int tid = 0; tid < NT_; ++tid) {      \
     auto& r = (ctx).regs[tid];               \
@@ -695,6 +710,290 @@ MVN_HD void fx_fused_lds_body(const StridedParams& P, long block, cfloat* lds, C
   MVN_PHASE(ctx, (fx_fu_mul<N>(buf, r, tid)));
   fx_dit<N, T, TP, false, NT, +1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_fu_store<N>(P, base, buf, tid)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Long lines (N > 1024): a 16-column tile (128-byte row segments) is twice what the LDS holds.
+// After stage 0 (radix 8, in registers) a line is 8 independent sub-lines of M0 = N/8 rows, so the
+// whole tile is kept in REGISTERS (8 * IT0 16-byte values per thread) and the inner stages run on
+// half of it at a time: sub-lines 0-3, then 4-7, each through a window of W = N/2 LDS rows.
+//   forward : loads, stage 0 -> [window r: registers -> LDS, inner stages, last stage -> stores] x 2
+//   inverse : [window r: loads + last stage -> LDS, inner stages, LDS -> registers] x 2 -> stage 0 -> stores
+// The 8-column form (64-byte segments, FxStridedCfg) ran these passes at 3.0-3.4 TB/s.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct FxSplitCfg {
+  static constexpr bool USE = N > 1024;
+  static constexpr int T = 16, TP = 16, CH = 8, TPQ = 8;
+  static constexpr int NS = fx_nstages(N);
+  static constexpr int M0 = fx_M(N, 0);
+  static constexpr int RL = fx_radix(N, NS - 1);
+  static constexpr int W = N / 2;  // rows per window = 4 sub-lines
+  static constexpr int NT1 = M0 * CH;
+  static constexpr int IT0 = fx_st_it0(NT1, 512);
+  static constexpr int NT = NT1 / IT0;
+  static constexpr int NWL = (W / RL) * CH;  // last-stage work items per window
+  static constexpr int ITL = (NWL + NT - 1) / NT;
+  static constexpr int TW1 = 0;  // the whole stage-ordered table sits behind the window
+  static constexpr int lds_cfloats = W * TP + (fx_twsize(N) - TW1);
+  static_assert(!USE || (fx_radix(N, 0) == 8 && NS >= 3 && N % 128 == 0 && W % RL == 0), "split plan");
+  static_assert(!USE || (NT % 64 == 0 && NT * IT0 == NT1), "split workgroup size");
+  static_assert(!USE || sizeof(cfloat) * lds_cfloats <= 160 * 1024, "window does not fit the LDS");
+};
+
+template <int N>
+struct FxSplitRegs {
+  qfloat a[8 * FxSplitCfg<N>::IT0];  // the whole tile: rows j2 + k M0 of IT0 work items
+};
+
+// an inner stage on one window (rows are window-relative; sub-lines never straddle windows)
+template <int N, int S, int SIGN, bool DIF>
+MVN_HD void fx_stage_q_win(cfloat* bufc, const cfloat* twl, int tid) {
+  typedef FxSplitCfg<N> C;
+  constexpr int R = fx_radix(N, S), M = fx_M(N, S), CH = C::CH, TPQ = C::TPQ, NT = C::NT;
+  static_assert(C::M0 % (R * M) == 0, "a stage's blocks must tile a sub-line");
+  constexpr int nwork = (C::W / R) * CH;
+  constexpr int iters = (nwork + NT - 1) / NT;
+  qfloat* buf = reinterpret_cast<qfloat*>(bufc);
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
+    const int w = tid + it * NT;
+    if (nwork % NT != 0 && w >= nwork) break;
+    const int b = w / CH, q = w % CH;
+    const int blk = b / M, j2 = b % M;
+    qfloat* p = buf + (blk * R * M + j2) * TPQ + q;
+    qfloat a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = p[j * M * TPQ];
+    cfloat tw[fx_rs(R)];
+    fx_tw_row<R>(twl + (fx_twoff(N, S) - C::TW1) + j2 * fx_rs(R), tw);
+    if (!DIF) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+    }
+    fx_dft_q<R, SIGN>(a);
+    if (DIF) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) p[j * M * TPQ] = a[j];
+    MVN_SCHED_FENCE();
+  }
+}
+
+template <int N, int SIGN, bool DIF, int S, int TO, typename Ctx>
+struct FxStagesQWin {
+  static MVN_HD void run(cfloat* buf, const cfloat* twl, Ctx& ctx) {
+    constexpr int NT_ = FxSplitCfg<N>::NT;
+    (void)NT_;
+    if constexpr (DIF ? (S <= TO) : (S >= TO)) {
+      MVN_PHASE(ctx, (fx_stage_q_win<N, S, SIGN, DIF>(buf, twl, tid)));
+      FxStagesQWin<N, SIGN, DIF, DIF ? S + 1 : S - 1, TO, Ctx>::run(buf, twl, ctx);
+    }
+  }
+};
+
+template <int N>
+MVN_HD void fx_sp_tables(const StridedParams& P, cfloat* twl, int tid) {
+  typedef FxSplitCfg<N> C;
+  fx_copy_table<C::NT>(twl, P.ax.tws + C::TW1, fx_twsize(N) - C::TW1, tid);
+}
+
+// forward: tile rows of work items [LO, HI) into registers
+template <int N, int LO, int HI>
+MVN_HD void fx_sp_load(const StridedParams& P, long base, FxSplitRegs<N>& r, int tid) {
+  typedef FxSplitCfg<N> C;
+  const cfloat* src0 = (P.src ? P.src : P.data) + base;
+  const long rstep = (long)C::M0 * P.estride;
+#pragma unroll
+  for (int it = LO; it < HI; ++it) {
+    const int w = tid + it * C::NT;
+    const int q = w % C::CH, j2 = w / C::CH;
+    long off = (long)j2 * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      r.a[it * 8 + k] = *reinterpret_cast<const qfloat*>(src0 + off);
+      off += rstep;
+      MVN_JIT_ADDRESS(off);
+    }
+  }
+}
+
+// forward stage 0 on the registers of work items [LO, HI) (twiddle rows from the LDS table)
+template <int N, int LO, int HI>
+MVN_HD void fx_sp_stage0(const cfloat* twl, FxSplitRegs<N>& r, int tid) {
+  typedef FxSplitCfg<N> C;
+#pragma unroll
+  for (int it = LO; it < HI; ++it) {
+    const int w = tid + it * C::NT;
+    const int j2 = w / C::CH;
+    cfloat tw[8];
+    fx_tw_row<8>(twl + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
+    qfloat a[8];  // a local copy: a pointer into r.a would keep the whole array in memory
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = r.a[it * 8 + k];
+    fx_dft_q<8, -1>(a);
+    r.a[it * 8] = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r.a[it * 8 + k] = fx_qmul_c(a[k], twdir<-1>(tw[k]));
+    MVN_SCHED_FENCE();
+  }
+}
+
+// registers <-> window WIN of the LDS (sub-lines 4 WIN .. 4 WIN + 3) for work items [LO, HI);
+// WIN is a template parameter so that every register index is a compile-time constant
+template <int N, bool TO_LDS, int WIN, int LO, int HI>
+MVN_HD void fx_sp_window(cfloat* buf, FxSplitRegs<N>& r, int tid) {
+  typedef FxSplitCfg<N> C;
+#pragma unroll
+  for (int it = LO; it < HI; ++it) {
+    const int w = tid + it * C::NT;
+    const int q = w % C::CH, j2 = w / C::CH;
+    qfloat* d = reinterpret_cast<qfloat*>(buf) + j2 * C::TPQ + q;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (TO_LDS)
+        d[kk * C::M0 * C::TPQ] = r.a[it * 8 + 4 * WIN + kk];
+      else
+        r.a[it * 8 + 4 * WIN + kk] = d[kk * C::M0 * C::TPQ];
+    }
+  }
+}
+
+// forward exit of a window: last stage in registers, stored straight to global memory
+template <int N>
+MVN_HD void fx_sp_last_store(const StridedParams& P, long base, const cfloat* buf, int win, int tid) {
+  typedef FxSplitCfg<N> C;
+  constexpr int CH = C::CH, RL = C::RL;
+#pragma unroll
+  for (int it = 0; it < C::ITL; ++it) {
+    const int w = tid + it * C::NT;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) break;
+    const int b = w / CH, q = w % CH;
+    const qfloat* s = reinterpret_cast<const qfloat*>(buf) + (b * RL) * C::TPQ + q;
+    qfloat a[RL];
+#pragma unroll
+    for (int k = 0; k < RL; ++k) a[k] = s[k * C::TPQ];
+    fx_dft_q<RL, -1>(a);
+    cfloat* dst0 = P.data + base;
+    long off = (long)(win * C::W + b * RL) * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) {
+      *reinterpret_cast<qfloat*>(dst0 + off) = a[k];
+      off += P.estride;
+      MVN_JIT_ADDRESS(off);
+    }
+    MVN_SCHED_FENCE();
+  }
+}
+
+// inverse entry of a window: loads with the last stage's mapping, that stage in registers
+template <int N>
+MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int win, int tid) {
+  typedef FxSplitCfg<N> C;
+  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
+  const cfloat* src0 = (P.src ? P.src : P.data) + base + (long)win * C::W * P.estride;
+  qfloat a[ITL * RL];
+#pragma unroll
+  for (int it = 0; it < ITL; ++it) {
+    int w = tid + it * C::NT;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;  // clamped: loaded, never used
+    const int b = w / CH, q = w % CH;
+    long off = (long)(b * RL) * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) {
+      a[it * RL + k] = *reinterpret_cast<const qfloat*>(src0 + off);
+      off += P.estride;
+      MVN_JIT_ADDRESS(off);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITL; ++it) {
+    const int w = tid + it * C::NT;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) break;
+    const int b = w / CH, q = w % CH;
+    qfloat x[RL];
+#pragma unroll
+    for (int k = 0; k < RL; ++k) x[k] = a[it * RL + k];
+    fx_dft_q<RL, +1>(x);
+    qfloat* d = reinterpret_cast<qfloat*>(buf) + (b * RL) * C::TPQ + q;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) d[k * C::TPQ] = x[k];
+    MVN_SCHED_FENCE();
+  }
+}
+
+// inverse exit: stage 0 (twiddles first) on the registers, stored to global memory
+template <int N>
+MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* twl,
+                               FxSplitRegs<N>& r, int tid) {
+  typedef FxSplitCfg<N> C;
+  const long rstep = (long)C::M0 * P.estride;
+#pragma unroll
+  for (int it = 0; it < C::IT0; ++it) {
+    const int w = tid + it * C::NT;
+    const int q = w % C::CH, j2 = w / C::CH;
+    cfloat tw[8];
+    fx_tw_row<8>(twl + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
+    qfloat a[8];
+    a[0] = r.a[it * 8];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(r.a[it * 8 + k], twdir<+1>(tw[k]));
+    fx_dft_q<8, +1>(a);
+    cfloat* dst0 = P.data + base;
+    long off = (long)j2 * P.estride + 2 * q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      *reinterpret_cast<qfloat*>(dst0 + off) = a[k];
+      off += rstep;
+      MVN_JIT_ADDRESS(off);
+    }
+    MVN_SCHED_FENCE();
+  }
+}
+
+// tiles first, first + step, ... < total (MODE is FWD or INV)
+template <int N, int MODE, typename Ctx>
+MVN_HD void fx_strided_split_body(const StridedParams& P, long first, long total, long step,
+                                  cfloat* lds, Ctx& ctx) {
+  typedef FxSplitCfg<N> C;
+  constexpr int NT_ = C::NT, NS = C::NS;
+  (void)NT_;
+  cfloat* buf = lds;
+  cfloat* twl = lds + C::W * C::TP;
+  if (first >= total) return;
+  MVN_PHASE(ctx, (fx_sp_tables<N>(P, twl, tid)));
+  for (long block = first; block < total; block += step) {
+    MVN_TILE_LOOP_TOP(ctx);
+    const unsigned o = (unsigned)block / (unsigned)P.tiles_per_outer;
+    const unsigned t = (unsigned)block - o * (unsigned)P.tiles_per_outer;
+    const long base = (long)o * P.ostride + (long)t * C::T;
+    if (MODE == MVN_ST_FWD) {
+      // in two groups of work items: with all of a tile's rows AND a butterfly's temporaries live at
+      // once the allocator spills the half of the tile that waits for window 1
+      constexpr int IA = (C::IT0 + 1) / 2;
+      MVN_PHASE_NOSYNC(ctx, (fx_sp_load<N, 0, IA>(P, base, r, tid)));
+      MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0<N, 0, IA>(twl, r, tid)));
+      MVN_PHASE_NOSYNC(ctx, (fx_sp_window<N, true, 0, 0, IA>(buf, r, tid), MVN_SCHED_FENCE()));
+      MVN_PHASE_NOSYNC(ctx, (fx_sp_load<N, IA, C::IT0>(P, base, r, tid)));
+      MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0<N, IA, C::IT0>(twl, r, tid)));
+      MVN_PHASE(ctx, (fx_sp_window<N, true, 0, IA, C::IT0>(buf, r, tid)));
+      FxStagesQWin<N, -1, true, 1, NS - 2, Ctx>::run(buf, twl, ctx);
+      MVN_PHASE(ctx, (fx_sp_last_store<N>(P, base, buf, 0, tid)));
+      MVN_PHASE(ctx, (fx_sp_window<N, true, 1, 0, C::IT0>(buf, r, tid)));
+      FxStagesQWin<N, -1, true, 1, NS - 2, Ctx>::run(buf, twl, ctx);
+      MVN_PHASE(ctx, (fx_sp_last_store<N>(P, base, buf, 1, tid)));
+    } else {
+      MVN_PHASE(ctx, (fx_sp_load_last<N>(P, base, buf, 0, tid)));
+      FxStagesQWin<N, +1, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
+      MVN_PHASE(ctx, (fx_sp_window<N, false, 0, 0, C::IT0>(buf, r, tid)));
+      MVN_PHASE(ctx, (fx_sp_load_last<N>(P, base, buf, 1, tid)));
+      FxStagesQWin<N, +1, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
+      MVN_PHASE(ctx, (fx_sp_window<N, false, 1, 0, C::IT0>(buf, r, tid)));
+      MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0_store<N>(P, base, twl, r, tid)));
+    }
+  }
 }
 
 // which body, register block and workgroup size a (length, mode) pair uses

@@ -19,6 +19,7 @@
 //                                   legacy entry points
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +109,14 @@ __global__ void __launch_bounds__((FxStridedSel<N, MODE>::NT), (FxStridedSel<N, 
   typename FxStridedSel<N, MODE>::Ctx ctx;
   ctx.tid = (int)threadIdx.x;
   FxStridedSel<N, MODE>::run(p, (long)blockIdx.x, p.nblocks, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
+}
+
+template <int N, int MODE>
+__global__ void __launch_bounds__((FxSplitCfg<N>::NT)) kx_strided_split(const StridedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<FxSplitRegs<N>, FxSplitCfg<N>::NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  fx_strided_split_body<N, MODE>(p, (long)blockIdx.x, p.nblocks, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
 __global__ void k_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
@@ -469,6 +478,47 @@ void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t
   }
 }
 
+static std::atomic<long> g_split_launches{0};
+long split_launch_count() { return g_split_launches.load(); }
+
+// long lines: 16-column tiles through the split-window body when the columns divide (the plan's
+// geometry is for the 8-column kernel); MVN_NO_SPLIT=1 keeps the 8-column kernel
+template <int N>
+static bool try_launch_split(int mode, const StridedParams& p, long nblocks, stream_t s) {
+  if constexpr (FxSplitCfg<N>::USE) {
+    typedef FxSplitCfg<N> C;
+    static const bool off = [] {
+      const char* e = std::getenv("MVN_NO_SPLIT");
+      return e && *e && std::strcmp(e, "0") != 0;
+    }();
+    // the forward form still spills (all of a tile's rows and a butterfly's temporaries are live
+    // together at its start: 4.1 ms vs 2.8 ms on 1920-lines) and stays on the 8-column kernel
+    // unless MVN_SPLIT_FWD=1; the inverse form gains 23-27 % (3.1 -> 2.4 ms)
+    static const bool fwd_on = [] {
+      const char* e = std::getenv("MVN_SPLIT_FWD");
+      return e && *e && std::strcmp(e, "0") != 0;
+    }();
+    if (off || mode == MVN_ST_FWD_MUL_INV || (mode == MVN_ST_FWD && !fwd_on) || p.cstride != 1 ||
+        p.ncols % C::T != 0 || p.tiles_per_outer < 1)
+      return false;
+    StridedParams q = p;
+    const long outer = nblocks / p.tiles_per_outer;
+    q.tiles_per_outer = p.ncols / C::T;
+    q.T = q.TP = C::T;
+    const long nb = outer * q.tiles_per_outer;
+    const size_t lds = sizeof(cfloat) * (size_t)C::lds_cfloats;
+    ++g_split_launches;
+    if (mode == MVN_ST_FWD)
+      launch_walking(kx_strided_split<N, MVN_ST_FWD>, q, nb, C::NT, lds, s, true);
+    else
+      launch_walking(kx_strided_split<N, MVN_ST_INV>, q, nb, C::NT, lds, s, true);
+    return true;
+  } else {
+    (void)mode; (void)p; (void)nblocks; (void)s;
+    return false;
+  }
+}
+
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
                     size_t lds_bytes, stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
@@ -478,6 +528,7 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
     switch (p.ax.n) {
 #define X(N)                                                                                       \
   case N:                                                                                          \
+    if (try_launch_split<N>(mode, p, nblocks, s)) return;                                          \
     if (mode == MVN_ST_FWD) launch_walking(kx_strided<N, MVN_ST_FWD>, p, nblocks, FxStridedSel<N, MVN_ST_FWD>::NT, lds_bytes, s, true); \
     else if (mode == MVN_ST_INV) launch_walking(kx_strided<N, MVN_ST_INV>, p, nblocks, FxStridedSel<N, MVN_ST_INV>::NT, lds_bytes, s, true); \
     else launch_walking(kx_strided<N, MVN_ST_FWD_MUL_INV>, p, nblocks, FxStridedSel<N, MVN_ST_FWD_MUL_INV>::NT, lds_bytes, s, !FxStridedSel<N, MVN_ST_FWD_MUL_INV>::LDS_FUSED); \

@@ -28,7 +28,7 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
@@ -62,6 +62,8 @@ class Binding:
         i3 = C.POINTER(C.c_int)
         l.mvn_last_error.restype = C.c_char_p
         l.mvn_backend_name.restype = C.c_char_p
+        l.mvn_split_launch_count.restype = C.c_long
+        l.mvn_split_launch_count.argtypes = []
         l.mvn_kernel_kind_name.restype = C.c_char_p
         l.mvn_kernel_kind_name.argtypes = [C.c_int]
         l.inplace_gpu_deconvolve.argtypes = [c_float_p, Workspace, C.c_int]

@@ -798,3 +798,19 @@ def test_graph_replayed_sweeps_equal_direct_launches(gpu, shape, tmp_path):
         assert np.all(np.isfinite(ref))
         assert np.array_equal(got[i], ref)
     e.close()
+
+
+@pytest.mark.gpu
+def test_long_lines_use_the_split_window_kernels(gpu):
+    # lines above 1024 keep 16-column tiles by holding the tile in registers and running the inner
+    # stages on half of it at a time (mvn_fixed.hpp, FxSplitCfg); inverse passes by default
+    rng = np.random.default_rng(3)
+    for shape in ((2, 1920, 64), (1280, 16, 64)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        c0 = gpu.l.mvn_split_launch_count()
+        spec = gpu.rfft3(x)
+        y = gpu.irfft3(spec, shape[2])
+        assert gpu.l.mvn_split_launch_count() - c0 >= 1
+        ref = np.fft.rfftn(x.astype(np.float64))
+        assert np.abs(spec - ref).max() <= 2e-6 * np.abs(ref).max()
+        assert np.abs(y / x.size - x).max() <= 1e-5

@@ -717,8 +717,7 @@ MVN_HD void fx_fused_lds_body(const StridedParams& P, long block, cfloat* lds, C
 // After stage 0 (radix 8, in registers) a line is 8 independent sub-lines of M0 = N/8 rows, so the
 // whole tile is kept in REGISTERS (8 * IT0 16-byte values per thread) and the inner stages run on
 // half of it at a time: sub-lines 0-3, then 4-7, each through a window of W = N/2 LDS rows.
-//   forward : loads, stage 0 -> [window r: registers -> LDS, inner stages, last stage -> stores] x 2
-//   inverse : [window r: loads + last stage -> LDS, inner stages, LDS -> registers] x 2 -> stage 0 -> stores
+//   [window r: loads + last stage -> LDS, inner stages, LDS -> registers] x 2 -> stage 0 -> stores
 // The 8-column form (64-byte segments, FxStridedCfg) ran these passes at 3.0-3.4 TB/s.
 // ---------------------------------------------------------------------------------------------
 template <int N>
@@ -735,6 +734,9 @@ struct FxSplitCfg {
   static constexpr int NWL = (W / RL) * CH;  // last-stage work items per window
   static constexpr int ITL = (NWL + NT - 1) / NT;
   static constexpr int TW1 = 0;  // the whole stage-ordered table sits behind the window
+  // measured: the forward form (row-permuted accesses, a little more register pressure) wins at
+  // 1280 (0.263 -> 0.246 ms) and loses at 1920 (2.77 -> 2.95 ms, 172 bytes of scratch)
+  static constexpr bool FWD_DEFAULT = N <= 1280;
   static constexpr int lds_cfloats = W * TP + (fx_twsize(N) - TW1);
   static_assert(!USE || (fx_radix(N, 0) == 8 && NS >= 3 && N % 128 == 0 && W % RL == 0), "split plan");
   static_assert(!USE || (NT % 64 == 0 && NT * IT0 == NT1), "split workgroup size");
@@ -800,111 +802,44 @@ MVN_HD void fx_sp_tables(const StridedParams& P, cfloat* twl, int tid) {
   fx_copy_table<C::NT>(twl, P.ax.tws + C::TW1, fx_twsize(N) - C::TW1, tid);
 }
 
-// forward: tile rows of work items [LO, HI) into registers
-template <int N, int LO, int HI>
-MVN_HD void fx_sp_load(const StridedParams& P, long base, FxSplitRegs<N>& r, int tid) {
+// LDS -> registers of window WIN (sub-lines 4 WIN .. 4 WIN + 3); WIN is a template parameter so
+// that every register index is a compile-time constant
+template <int N, int WIN>
+MVN_HD void fx_sp_collect(const cfloat* buf, FxSplitRegs<N>& r, int tid) {
   typedef FxSplitCfg<N> C;
-  const cfloat* src0 = (P.src ? P.src : P.data) + base;
-  const long rstep = (long)C::M0 * P.estride;
 #pragma unroll
-  for (int it = LO; it < HI; ++it) {
+  for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * C::NT;
     const int q = w % C::CH, j2 = w / C::CH;
-    long off = (long)j2 * P.estride + 2 * q;
+    const qfloat* d = reinterpret_cast<const qfloat*>(buf) + j2 * C::TPQ + q;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      r.a[it * 8 + k] = *reinterpret_cast<const qfloat*>(src0 + off);
-      off += rstep;
-      MVN_JIT_ADDRESS(off);
-    }
+    for (int kk = 0; kk < 4; ++kk) r.a[it * 8 + 4 * WIN + kk] = d[kk * C::M0 * C::TPQ];
   }
 }
 
-// forward stage 0 on the registers of work items [LO, HI) (twiddle rows from the LDS table)
-template <int N, int LO, int HI>
-MVN_HD void fx_sp_stage0(const cfloat* twl, FxSplitRegs<N>& r, int tid) {
-  typedef FxSplitCfg<N> C;
-#pragma unroll
-  for (int it = LO; it < HI; ++it) {
-    const int w = tid + it * C::NT;
-    const int j2 = w / C::CH;
-    cfloat tw[8];
-    fx_tw_row<8>(twl + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
-    qfloat a[8];  // a local copy: a pointer into r.a would keep the whole array in memory
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = r.a[it * 8 + k];
-    fx_dft_q<8, -1>(a);
-    r.a[it * 8] = a[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) r.a[it * 8 + k] = fx_qmul_c(a[k], twdir<-1>(tw[k]));
-    MVN_SCHED_FENCE();
-  }
-}
-
-// registers <-> window WIN of the LDS (sub-lines 4 WIN .. 4 WIN + 3) for work items [LO, HI);
-// WIN is a template parameter so that every register index is a compile-time constant
-template <int N, bool TO_LDS, int WIN, int LO, int HI>
-MVN_HD void fx_sp_window(cfloat* buf, FxSplitRegs<N>& r, int tid) {
-  typedef FxSplitCfg<N> C;
-#pragma unroll
-  for (int it = LO; it < HI; ++it) {
-    const int w = tid + it * C::NT;
-    const int q = w % C::CH, j2 = w / C::CH;
-    qfloat* d = reinterpret_cast<qfloat*>(buf) + j2 * C::TPQ + q;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (TO_LDS)
-        d[kk * C::M0 * C::TPQ] = r.a[it * 8 + 4 * WIN + kk];
-      else
-        r.a[it * 8 + 4 * WIN + kk] = d[kk * C::M0 * C::TPQ];
-    }
-  }
-}
-
-// forward exit of a window: last stage in registers, stored straight to global memory
-template <int N>
-MVN_HD void fx_sp_last_store(const StridedParams& P, long base, const cfloat* buf, int win, int tid) {
-  typedef FxSplitCfg<N> C;
-  constexpr int CH = C::CH, RL = C::RL;
-#pragma unroll
-  for (int it = 0; it < C::ITL; ++it) {
-    const int w = tid + it * C::NT;
-    if (C::NWL % C::NT != 0 && w >= C::NWL) break;
-    const int b = w / CH, q = w % CH;
-    const qfloat* s = reinterpret_cast<const qfloat*>(buf) + (b * RL) * C::TPQ + q;
-    qfloat a[RL];
-#pragma unroll
-    for (int k = 0; k < RL; ++k) a[k] = s[k * C::TPQ];
-    fx_dft_q<RL, -1>(a);
-    cfloat* dst0 = P.data + base;
-    long off = (long)(win * C::W + b * RL) * P.estride + 2 * q;
-#pragma unroll
-    for (int k = 0; k < RL; ++k) {
-      *reinterpret_cast<qfloat*>(dst0 + off) = a[k];
-      off += P.estride;
-      MVN_JIT_ADDRESS(off);
-    }
-    MVN_SCHED_FENCE();
-  }
-}
-
-// inverse entry of a window: loads with the last stage's mapping, that stage in registers
-template <int N>
+// entry of a window: loads with the last stage's mapping (positions win W + b RL + k), that
+// stage (M = 1, no twiddles) in registers.  PERM: position p is fetched from row rev(p) -- the
+// forward transform reads its natural-order input in digit-reversed order.
+template <int N, int SIGN, bool PERM>
 MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int win, int tid) {
   typedef FxSplitCfg<N> C;
   constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
-  const cfloat* src0 = (P.src ? P.src : P.data) + base + (long)win * C::W * P.estride;
+  const cfloat* src0 = (P.src ? P.src : P.data) + base;
+  // the last digit has weight W_last in the natural index: the RL rows of an item are equally
+  // spaced either way
+  const long kstep = PERM ? (long)fx_W(N, C::NS - 1) * P.estride : P.estride;
   qfloat a[ITL * RL];
 #pragma unroll
   for (int it = 0; it < ITL; ++it) {
     int w = tid + it * C::NT;
     if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;  // clamped: loaded, never used
     const int b = w / CH, q = w % CH;
-    long off = (long)(b * RL) * P.estride + 2 * q;
+    const int pos = win * C::W + b * RL;
+    long off = (long)(PERM ? fx_rev<N>(pos) : pos) * P.estride + 2 * q;
 #pragma unroll
     for (int k = 0; k < RL; ++k) {
       a[it * RL + k] = *reinterpret_cast<const qfloat*>(src0 + off);
-      off += P.estride;
+      off += kstep;
       MVN_JIT_ADDRESS(off);
     }
   }
@@ -916,7 +851,7 @@ MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int 
     qfloat x[RL];
 #pragma unroll
     for (int k = 0; k < RL; ++k) x[k] = a[it * RL + k];
-    fx_dft_q<RL, +1>(x);
+    fx_dft_q<RL, SIGN>(x);
     qfloat* d = reinterpret_cast<qfloat*>(buf) + (b * RL) * C::TPQ + q;
 #pragma unroll
     for (int k = 0; k < RL; ++k) d[k * C::TPQ] = x[k];
@@ -924,41 +859,55 @@ MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int 
   }
 }
 
-// inverse exit: stage 0 (twiddles first) on the registers, stored to global memory
-template <int N>
+// exit: stage 0 (twiddles first) on the registers, stored to global memory.  PERM: natural index
+// n = j2 + k M0 goes to row inv(n) -- the forward transform leaves its spectrum in position order.
+template <int N, int SIGN, bool PERM>
 MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* twl,
                                FxSplitRegs<N>& r, int tid) {
   typedef FxSplitCfg<N> C;
   const long rstep = (long)C::M0 * P.estride;
+  cfloat* dst0 = P.data + base;
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * C::NT;
     const int q = w % C::CH, j2 = w / C::CH;
     cfloat tw[8];
     fx_tw_row<8>(twl + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
-    qfloat a[8];
+    qfloat a[8];  // a local copy: a pointer into r.a would keep the whole array in memory
     a[0] = r.a[it * 8];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(r.a[it * 8 + k], twdir<+1>(tw[k]));
-    fx_dft_q<8, +1>(a);
-    cfloat* dst0 = P.data + base;
-    long off = (long)j2 * P.estride + 2 * q;
+    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(r.a[it * 8 + k], twdir<SIGN>(tw[k]));
+    fx_dft_q<8, SIGN>(a);
+    if (PERM) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      *reinterpret_cast<qfloat*>(dst0 + off) = a[k];
-      off += rstep;
-      MVN_JIT_ADDRESS(off);
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<qfloat*>(dst0 + (long)fx_inv<N>(j2 + k * C::M0) * P.estride + 2 * q) = a[k];
+    } else {
+      long off = (long)j2 * P.estride + 2 * q;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        *reinterpret_cast<qfloat*>(dst0 + off) = a[k];
+        off += rstep;
+        MVN_JIT_ADDRESS(off);
+      }
     }
     MVN_SCHED_FENCE();
   }
 }
 
-// tiles first, first + step, ... < total (MODE is FWD or INV)
+// tiles first, first + step, ... < total (MODE is FWD or INV).  Both directions are decimation in
+// time -- the tile ACCUMULATES in registers window by window, so the registers fill up only at
+// the end (a decimation-in-frequency forward form, with every row live from the start, spilled
+// 320 bytes per thread and lost 45 %).  The forward transform gets its digit-reversed input and
+// its position-ordered output by permuting whole rows in the global accesses, which costs
+// nothing for 128-byte row segments.
 template <int N, int MODE, typename Ctx>
 MVN_HD void fx_strided_split_body(const StridedParams& P, long first, long total, long step,
                                   cfloat* lds, Ctx& ctx) {
   typedef FxSplitCfg<N> C;
   constexpr int NT_ = C::NT, NS = C::NS;
+  constexpr int SIGN = MODE == MVN_ST_FWD ? -1 : +1;
+  constexpr bool PERM = MODE == MVN_ST_FWD;
   (void)NT_;
   cfloat* buf = lds;
   cfloat* twl = lds + C::W * C::TP;
@@ -969,30 +918,13 @@ MVN_HD void fx_strided_split_body(const StridedParams& P, long first, long total
     const unsigned o = (unsigned)block / (unsigned)P.tiles_per_outer;
     const unsigned t = (unsigned)block - o * (unsigned)P.tiles_per_outer;
     const long base = (long)o * P.ostride + (long)t * C::T;
-    if (MODE == MVN_ST_FWD) {
-      // in two groups of work items: with all of a tile's rows AND a butterfly's temporaries live at
-      // once the allocator spills the half of the tile that waits for window 1
-      constexpr int IA = (C::IT0 + 1) / 2;
-      MVN_PHASE_NOSYNC(ctx, (fx_sp_load<N, 0, IA>(P, base, r, tid)));
-      MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0<N, 0, IA>(twl, r, tid)));
-      MVN_PHASE_NOSYNC(ctx, (fx_sp_window<N, true, 0, 0, IA>(buf, r, tid), MVN_SCHED_FENCE()));
-      MVN_PHASE_NOSYNC(ctx, (fx_sp_load<N, IA, C::IT0>(P, base, r, tid)));
-      MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0<N, IA, C::IT0>(twl, r, tid)));
-      MVN_PHASE(ctx, (fx_sp_window<N, true, 0, IA, C::IT0>(buf, r, tid)));
-      FxStagesQWin<N, -1, true, 1, NS - 2, Ctx>::run(buf, twl, ctx);
-      MVN_PHASE(ctx, (fx_sp_last_store<N>(P, base, buf, 0, tid)));
-      MVN_PHASE(ctx, (fx_sp_window<N, true, 1, 0, C::IT0>(buf, r, tid)));
-      FxStagesQWin<N, -1, true, 1, NS - 2, Ctx>::run(buf, twl, ctx);
-      MVN_PHASE(ctx, (fx_sp_last_store<N>(P, base, buf, 1, tid)));
-    } else {
-      MVN_PHASE(ctx, (fx_sp_load_last<N>(P, base, buf, 0, tid)));
-      FxStagesQWin<N, +1, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
-      MVN_PHASE(ctx, (fx_sp_window<N, false, 0, 0, C::IT0>(buf, r, tid)));
-      MVN_PHASE(ctx, (fx_sp_load_last<N>(P, base, buf, 1, tid)));
-      FxStagesQWin<N, +1, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
-      MVN_PHASE(ctx, (fx_sp_window<N, false, 1, 0, C::IT0>(buf, r, tid)));
-      MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0_store<N>(P, base, twl, r, tid)));
-    }
+    MVN_PHASE(ctx, (fx_sp_load_last<N, SIGN, PERM>(P, base, buf, 0, tid)));
+    FxStagesQWin<N, SIGN, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
+    MVN_PHASE(ctx, (fx_sp_collect<N, 0>(buf, r, tid)));
+    MVN_PHASE(ctx, (fx_sp_load_last<N, SIGN, PERM>(P, base, buf, 1, tid)));
+    FxStagesQWin<N, SIGN, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
+    MVN_PHASE(ctx, (fx_sp_collect<N, 1>(buf, r, tid)));
+    MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0_store<N, SIGN, PERM>(P, base, twl, r, tid)));
   }
 }
 

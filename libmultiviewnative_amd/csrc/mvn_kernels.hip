@@ -491,14 +491,12 @@ static bool try_launch_split(int mode, const StridedParams& p, long nblocks, str
       const char* e = std::getenv("MVN_NO_SPLIT");
       return e && *e && std::strcmp(e, "0") != 0;
     }();
-    // the forward form still spills (all of a tile's rows and a butterfly's temporaries are live
-    // together at its start: 4.1 ms vs 2.8 ms on 1920-lines) and stays on the 8-column kernel
-    // unless MVN_SPLIT_FWD=1; the inverse form gains 23-27 % (3.1 -> 2.4 ms)
-    static const bool fwd_on = [] {
+    static const int fwd_env = [] {  // MVN_SPLIT_FWD=0/1 overrides the per-length default
       const char* e = std::getenv("MVN_SPLIT_FWD");
-      return e && *e && std::strcmp(e, "0") != 0;
+      return e && *e ? (std::strcmp(e, "0") != 0 ? 1 : 0) : -1;
     }();
-    if (off || mode == MVN_ST_FWD_MUL_INV || (mode == MVN_ST_FWD && !fwd_on) || p.cstride != 1 ||
+    const bool fwd_ok = fwd_env < 0 ? C::FWD_DEFAULT : fwd_env == 1;
+    if (off || mode == MVN_ST_FWD_MUL_INV || (mode == MVN_ST_FWD && !fwd_ok) || p.cstride != 1 ||
         p.ncols % C::T != 0 || p.tiles_per_outer < 1)
       return false;
     StridedParams q = p;

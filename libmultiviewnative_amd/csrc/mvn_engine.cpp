@@ -879,7 +879,9 @@ void Engine::compute_delta(double lambda, float min_value) {
   be::set_device(device_);
   delta_ptr();
   const Plan3D& P = *plan_;
-  Profiler* prof = prof_.enabled ? &prof_ : nullptr;
+  // event pairs around every launch cost ~3 % of a sweep: sample like iterate() does
+  const int every = prof_.sample_every > 0 ? prof_.sample_every : 1;
+  Profiler* prof = (prof_.enabled && (pair_counter_++ % every) == 0) ? &prof_ : nullptr;
   cfloat* W = (cfloat*)work_;
   if (!psi_spec_) {
     psi_spec_ = (float*)be::dmalloc(P.main_bytes());
@@ -896,6 +898,7 @@ void Engine::compute_delta(double lambda, float min_value) {
   for (int v = 0; v < (int)views_.size(); ++v) {
     const ViewSlot& s = views_[(size_t)v];
     if (!s.set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
+    prof = (prof_.enabled && (pair_counter_++ % every) == 0) ? &prof_ : nullptr;
     EpilogueParams e1;
     std::memset(&e1, 0, sizeof(e1));
     e1.mode = MVN_EPI_DIVIDE;

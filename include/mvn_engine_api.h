@@ -81,6 +81,24 @@ MVN_API int mvn_engine_iterate(mvn_engine* e, int iterations, double lambda, flo
  * views; the caller all-reduces the delta buffer across ranks, then applies it */
 MVN_API int mvn_engine_compute_delta(mvn_engine* e, double lambda, float min_value);
 MVN_API int mvn_engine_apply_delta(mvn_engine* e);
+/* The same step in pieces, so that the all-reduce runs under the compute.  The
+ * correction leaves the LAST pass of the last local view and is consumed by plane-local passes
+ * (psi += delta, then the forward last-axis and dim1 passes of the next step), so both ends go
+ * chunk by chunk over ranges of dim0 planes:
+ *   n = mvn_engine_delta_chunks(e, wanted)        (<= wanted; tile alignment of the shape)
+ *   mvn_engine_compute_delta_head(e, lambda, minValue)
+ *   for c in 0..n-1: mvn_engine_compute_delta_chunk(e, c, n); start all-reduce of floats
+ *                    [first, first + count) of the delta buffer (mvn_engine_delta_chunk_range)
+ *   for c in 0..n-1: wait for chunk c's all-reduce; mvn_engine_apply_delta_chunk(e, c, n, feed_next)
+ * feed_next != 0 also leaves psi's transformed spectrum for the next _head call (another step
+ * follows).  Everything is asynchronous on mvn_engine_stream(); an engine created with 0 views
+ * contributes zeros (a rank without views still holds a replica of psi). */
+MVN_API int mvn_engine_delta_chunks(mvn_engine* e, int wanted);
+MVN_API int mvn_engine_delta_chunk_range(mvn_engine* e, int c, int n, size_t* first_float,
+                                         size_t* n_floats);
+MVN_API int mvn_engine_compute_delta_head(mvn_engine* e, double lambda, float min_value);
+MVN_API int mvn_engine_compute_delta_chunk(mvn_engine* e, int c, int n);
+MVN_API int mvn_engine_apply_delta_chunk(mvn_engine* e, int c, int n, int feed_next);
 MVN_API int mvn_engine_delta_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);
 /* make the engine write its delta into caller-owned DEVICE memory (same size as the engine's
  * own buffer) so a collective library can reduce it in place; NULL restores the internal one */

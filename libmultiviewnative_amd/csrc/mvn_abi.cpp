@@ -973,6 +973,34 @@ int mvn_engine_apply_delta(mvn_engine* e) {
   MVN_ENGINE_CALL("mvn_engine_apply_delta", E.apply_delta());
 }
 
+int mvn_engine_delta_chunks(mvn_engine* e, int wanted) {
+  int n = 1;
+  int rc = guarded("mvn_engine_delta_chunks", [&] {
+    if (!e || !e->impl) throw std::invalid_argument("null engine");
+    n = e->impl->delta_chunks(wanted);
+  });
+  return rc < 0 ? rc : n;
+}
+
+int mvn_engine_delta_chunk_range(mvn_engine* e, int c, int n, size_t* first_float, size_t* n_floats) {
+  MVN_ENGINE_CALL("mvn_engine_delta_chunk_range", {
+    if (!first_float || !n_floats) throw std::invalid_argument("null argument");
+    E.delta_chunk_range(c, n, first_float, n_floats);
+  });
+}
+
+int mvn_engine_compute_delta_head(mvn_engine* e, double lambda, float min_value) {
+  MVN_ENGINE_CALL("mvn_engine_compute_delta_head", E.compute_delta_head(lambda, min_value));
+}
+
+int mvn_engine_compute_delta_chunk(mvn_engine* e, int c, int n) {
+  MVN_ENGINE_CALL("mvn_engine_compute_delta_chunk", E.compute_delta_chunk(c, n));
+}
+
+int mvn_engine_apply_delta_chunk(mvn_engine* e, int c, int n, int feed_next) {
+  MVN_ENGINE_CALL("mvn_engine_apply_delta_chunk", E.apply_delta_chunk(c, n, feed_next != 0));
+}
+
 int mvn_engine_delta_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats) {
   MVN_ENGINE_CALL("mvn_engine_delta_ptr", {
     *dev_ptr = E.delta_ptr();

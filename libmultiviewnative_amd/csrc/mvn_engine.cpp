@@ -224,8 +224,22 @@ Plan3D::Plan3D(int dev, int d0, int d1, int d2)
 
 Plan3D::~Plan3D() { be::dfree(twr); }
 
+// a range of rows of a last-axis pass: whole tiles where the kernels need them
+static long rows_in_range(const Plan3D& P, long row0, long nrows) {
+  const long all = (long)P.L.rows;
+  const long n = nrows < 0 ? all - row0 : nrows;
+  if (row0 < 0 || n < 1 || row0 + n > all) throw std::out_of_range("mvn: row range of a last-axis pass");
+  if (P.rows_need_full_tiles() && (row0 % P.rows_tile() || n % P.rows_tile()))
+    throw std::logic_error("mvn: a row range of the fixed last-axis kernels must be whole tiles");
+  return n;
+}
+
 void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::stream_t s,
-                      Profiler* prof) const {
+                      Profiler* prof, long row0, long nrows) const {
+  const long R = rows_in_range(*this, row0, nrows);
+  in_real += row0 * L.RP;
+  out += row0 * L.C;
+  if (out_nyq) out_nyq += row0;
   RowsParams p;
   std::memset(&p, 0, sizeof(p));
   p.ax = ax2.view;
@@ -234,7 +248,7 @@ void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::st
   p.h = L.h;
   p.C = L.C;
   p.RP = L.RP;
-  p.rows = (long)L.rows;
+  p.rows = R;
   p.T = g_rows.T;
   p.TP = g_rows.TP;
   p.lds_alt = g_rows.lds_alt;
@@ -248,15 +262,26 @@ void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::st
   if (fx_rows) {
     p.fixed = 1;
     p.T = gx_rows.T;
-    be::launch_rows_r2c(p, true, (long)L.rows / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
+    be::launch_rows_r2c(p, true, R / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
     return;
   }
-  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
+  const long ntiles = (R + p.T - 1) / p.T;
   be::launch_rows_r2c(p, L.even, ntiles, g_rows.threads, g_rows.lds_bytes, s);
 }
 
 void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
-                      const EpilogueParams& epi, be::stream_t s, Profiler* prof) const {
+                      const EpilogueParams& epi_all, be::stream_t s, Profiler* prof, long row0,
+                      long nrows) const {
+  const long R = rows_in_range(*this, row0, nrows);
+  in += row0 * L.C;
+  if (in_nyq) in_nyq += row0;
+  if (out_real) out_real += row0 * L.RP;
+  EpilogueParams epi = epi_all;
+  const long eoff = row0 * L.RP;
+  if (epi.view) epi.view += eoff;
+  if (epi.psi) epi.psi += eoff;
+  if (epi.weights) epi.weights += eoff;
+  if (epi.delta) epi.delta += eoff;
   RowsParams p;
   std::memset(&p, 0, sizeof(p));
   p.ax = ax2.view;
@@ -265,7 +290,7 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   p.h = L.h;
   p.C = L.C;
   p.RP = L.RP;
-  p.rows = (long)L.rows;
+  p.rows = R;
   p.T = g_rows.T;
   p.TP = g_rows.TP;
   p.lds_alt = g_rows.lds_alt;
@@ -280,10 +305,10 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   if (fx_rows) {
     p.fixed = 1;
     p.T = gx_rows.T;
-    be::launch_rows_c2r(p, true, (long)L.rows / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
+    be::launch_rows_c2r(p, true, R / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
     return;
   }
-  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
+  const long ntiles = (R + p.T - 1) / p.T;
   be::launch_rows_c2r(p, L.even, ntiles, g_rows.threads, g_rows.lds_bytes, s);
 }
 
@@ -366,19 +391,23 @@ void SideStream::join_into(be::stream_t main) {
 }
 
 void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof,
-                   be::stream_t s_nyq) const {
+                   be::stream_t s_nyq, int z0, int nz) const {
   if (!s_nyq) s_nyq = s;
+  if (nz < 0) nz = L.d0 - z0;
+  if (z0 < 0 || nz < 1 || z0 + nz > L.d0) throw std::out_of_range("mvn: plane range of a dim1 pass");
+  data += (size_t)z0 * L.d1 * L.C;
+  if (nyq) nyq += (size_t)z0 * L.d1;
   {
     // main array [d0][d1][C]: lines along d1, tiles of neighbouring bins
     const PassGeom& g = fx_ax1 ? gx_ax1 : g_ax1;
     StridedParams p = make_strided(ax1, g, data, nullptr, (long)L.d1 * L.C, L.C, 1, L.C);
     p.fixed = fx_ax1 ? 1 : 0;
     ProfScope ps(prof, mode == MVN_ST_FWD ? KK_AXIS1_FWD : KK_AXIS1_INV, s);
-    be::launch_strided(mode, p, (long)L.d0 * p.tiles_per_outer, g.threads, g.lds_bytes, s);
+    be::launch_strided(mode, p, (long)nz * p.tiles_per_outer, g.threads, g.lds_bytes, s);
   }
   if (L.even) {
     // Nyquist plane [d0][d1]: lines along d1 are contiguous, neighbouring lines d1 apart
-    StridedParams p = make_strided(ax1, g_nyq1, nyq, nullptr, 0, 1, L.d1, L.d0);
+    StridedParams p = make_strided(ax1, g_nyq1, nyq, nullptr, 0, 1, L.d1, nz);
     p.is_nyq = 1;
     ProfScope ps(s_nyq == s ? prof : nullptr, KK_NYQ, s_nyq);
     be::launch_strided(mode, p, p.tiles_per_outer, g_nyq1.threads, g_nyq1.lds_bytes, s_nyq);
@@ -524,7 +553,9 @@ void PlanStore::clear() {
 // Engine
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device) {
-  if (num_views < 1) throw std::invalid_argument("mvn: num_views must be >= 1");
+  // zero views: a rank of a view-sharded run that got none (6 views on 8 GPUs) still keeps a
+  // replica of psi and takes part in the all-reduce with a zero correction
+  if (num_views < 0) throw std::invalid_argument("mvn: num_views must be >= 0");
   be::set_device(device_);
   plan_ = PlanStore::get().add(device_, dims);
   stream_ = be::stream_create();
@@ -729,6 +760,7 @@ void Engine::wait_staged(int v) {
 
 void Engine::set_psi(const float* host) {
   be::set_device(device_);
+  psi_spec_valid_ = false;
   upload_volume(psi_, host, stream_);
   be::stream_sync(stream_);
 }
@@ -813,6 +845,7 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
 void Engine::iterate(int iterations, double lambda, float min_value) {
   be::set_device(device_);
   work_has_psi_spectrum_ = false;  // psi may have been replaced since the last call
+  psi_spec_valid_ = false;
   const int V = (int)views_.size();
   static const bool graphs_on = env_int("MVN_GRAPH", 0) != 0 && be::graphs_supported();
   static const size_t graph_max_bytes = (size_t)env_int("MVN_GRAPH_MAX_MB", 160) << 20;
@@ -876,8 +909,50 @@ void Engine::bind_delta(float* external) {
 // forward last-axis and dim1 passes are done ONCE and every view's first convolution starts at
 // the (out-of-place) dim0 pass: 7 full passes per view instead of 9.
 void Engine::compute_delta(double lambda, float min_value) {
+  compute_delta_head(lambda, min_value);
+  compute_delta_chunk(0, 1);
+}
+
+// planes [z0, z0 + nz) of chunk c of n
+void Engine::chunk_planes(int c, int n, int* z0, int* nz) const {
+  const int d0 = plan_->L.d0;
+  if (n < 1 || n > d0 || c < 0 || c >= n) throw std::out_of_range("mvn: delta chunk index");
+  const int a = (int)((long)c * d0 / n), b = (int)((long)(c + 1) * d0 / n);
+  *z0 = a;
+  *nz = b - a;
+}
+
+// the largest chunk count <= wanted whose plane boundaries fall on tile boundaries of the
+// last-axis passes (the fixed-length kernels work on whole tiles of T rows)
+int Engine::delta_chunks(int wanted) const {
+  const Layout& L = plan_->L;
+  int n = wanted < 1 ? 1 : (wanted > L.d0 ? L.d0 : wanted);
+  if (!plan_->rows_need_full_tiles()) return n;
+  const int T = plan_->rows_tile();
+  for (; n > 1; --n) {
+    bool ok = true;
+    for (int c = 1; c < n && ok; ++c) ok = (((long)c * L.d0 / n) * L.d1) % T == 0;
+    if (ok) break;
+  }
+  return n;
+}
+
+void Engine::delta_chunk_range(int c, int n, size_t* first_float, size_t* n_floats) const {
+  int z0 = 0, nz = 0;
+  chunk_planes(c, n, &z0, &nz);
+  const size_t plane = (size_t)plan_->L.d1 * (size_t)plan_->L.RP;
+  *first_float = (size_t)z0 * plane;
+  *n_floats = (size_t)nz * plane;
+}
+
+void Engine::compute_delta_head(double lambda, float min_value) {
   be::set_device(device_);
   delta_ptr();
+  tail_pending_ = false;
+  tail_prof_ = nullptr;
+  work_has_psi_spectrum_ = false;
+  const int V = (int)views_.size();
+  if (V == 0) return;  // a rank without views contributes a zero correction (compute_delta_chunk)
   const Plan3D& P = *plan_;
   // event pairs around every launch cost ~3 % of a sweep: sample like iterate() does
   const int every = prof_.sample_every > 0 ? prof_.sample_every : 1;
@@ -886,16 +961,20 @@ void Engine::compute_delta(double lambda, float min_value) {
   if (!psi_spec_) {
     psi_spec_ = (float*)be::dmalloc(P.main_bytes());
     if (P.nyq_bytes()) psi_spec_nyq_ = (cfloat*)be::dmalloc(P.nyq_bytes());
+    psi_spec_valid_ = false;
   }
   static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;
   const bool fuse = P.can_fuse_rows() && !no_fuse;
   static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;
   const bool use_side = !no_side && side_.s && P.L.even;
   be::stream_t sn = use_side ? side_.s : stream_;
-  P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);
-  if (use_side) side_.fork_from(stream_);
-  P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof, sn);
-  for (int v = 0; v < (int)views_.size(); ++v) {
+  if (!psi_spec_valid_) {  // else: left there chunk by chunk by apply_delta_chunk(.., feed_next)
+    P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);
+    if (use_side) side_.fork_from(stream_);
+    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof, sn);
+  }
+  psi_spec_valid_ = false;  // consumed by this step; psi changes when the correction is applied
+  for (int v = 0; v < V; ++v) {
     const ViewSlot& s = views_[(size_t)v];
     if (!s.set) throw std::runtime_error("mvn: view " + std::to_string(v) + " was never set");
     prof = (prof_.enabled && (pair_counter_++ % every) == 0) ? &prof_ : nullptr;
@@ -917,8 +996,9 @@ void Engine::compute_delta(double lambda, float min_value) {
     e2.lambda_inv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
     e2.min_value = min_value;
     // convolution 1 from the shared spectrum of psi; the Nyquist-plane launches ride on the side
-    // stream (forked again per view: the previous view's last pass still reads work_nyq_)
-    if (use_side && v > 0) side_.fork_from(stream_);
+    // stream (forked per view: the previous view's last pass still reads work_nyq_, and the
+    // chunk-fed spectrum of psi was written on the main stream)
+    if (use_side) side_.fork_from(stream_);
     P.axis0(MVN_ST_FWD_MUL_INV, W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
             (const cfloat*)psi_spec_, psi_spec_nyq_);
     P.axis1(MVN_ST_INV, W, work_nyq_, stream_, prof, sn);
@@ -931,12 +1011,67 @@ void Engine::compute_delta(double lambda, float min_value) {
     }
     P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof,
                     use_side ? &side_ : nullptr);
-    P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
+    if (v + 1 < V) {
+      P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
+    } else {  // the last view's final pass is launched chunk by chunk (compute_delta_chunk)
+      tail_epi_ = e2;
+      tail_prof_ = prof;
+      tail_pending_ = true;
+    }
+  }
+}
+
+void Engine::compute_delta_chunk(int c, int n) {
+  be::set_device(device_);
+  int z0 = 0, nz = 0;
+  chunk_planes(c, n, &z0, &nz);
+  const Layout& L = plan_->L;
+  if (views_.empty()) {
+    size_t off = 0, cnt = 0;
+    delta_chunk_range(c, n, &off, &cnt);
+    be::dzero(delta_ptr() + off, cnt * sizeof(float), stream_);
+    return;
+  }
+  if (!tail_pending_) throw std::logic_error("mvn: compute_delta_chunk without compute_delta_head");
+  plan_->rows_c2r((const cfloat*)work_, work_nyq_, psi_, tail_epi_, stream_, c == 0 ? tail_prof_ : nullptr,
+                  (long)z0 * L.d1, (long)nz * L.d1);
+  if (c == n - 1) tail_pending_ = false;
+}
+
+void Engine::apply_delta_chunk(int c, int n, bool feed_next) {
+  be::set_device(device_);
+  int z0 = 0, nz = 0;
+  chunk_planes(c, n, &z0, &nz);
+  size_t off = 0, cnt = 0;
+  delta_chunk_range(c, n, &off, &cnt);
+  const Plan3D& P = *plan_;
+  work_has_psi_spectrum_ = false;
+  psi_spec_valid_ = false;
+  if (fed_n_ != n) {  // a new round of chunks (any order within a round)
+    fed_n_ = n;
+    fed_ = 0;
+  }
+  be::launch_axpy1(psi_ + off, delta_ptr() + off, cnt, stream_);
+  if (feed_next && !views_.empty()) {
+    if (!psi_spec_) {
+      psi_spec_ = (float*)be::dmalloc(P.main_bytes());
+      if (P.nyq_bytes()) psi_spec_nyq_ = (cfloat*)be::dmalloc(P.nyq_bytes());
+    }
+    P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, nullptr, (long)z0 * P.L.d1,
+               (long)nz * P.L.d1);
+    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, nullptr, stream_, z0, nz);
+    if (++fed_ == n) {  // every plane of the spectrum belongs to the new psi
+      psi_spec_valid_ = true;
+      fed_ = 0;
+    }
+  } else {
+    fed_ = 0;
   }
 }
 
 void Engine::apply_delta() {
   be::set_device(device_);
+  psi_spec_valid_ = false;
   be::launch_axpy1(psi_, delta_ptr(), plan_->L.real_floats(), stream_);
 }
 

@@ -115,10 +115,18 @@ class Plan3D {
   size_t nyq_bytes() const { return L.nyq_cplx() * sizeof(cfloat); }
 
   // last-axis passes
+  // `row0` / `nrows` (default: all d0*d1 rows) restrict a pass to a range of rows: every array a
+  // last-axis pass touches is indexed by row, so a range is the same launch on shifted pointers.
+  // The view-sharded driver uses it to produce and consume the correction chunk by chunk under
+  // the all-reduce (Engine::compute_delta_chunk / apply_delta_chunk).
   void rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::stream_t s,
-                Profiler* prof = nullptr) const;
+                Profiler* prof = nullptr, long row0 = 0, long nrows = -1) const;
   void rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
-                const EpilogueParams& epi, be::stream_t s, Profiler* prof = nullptr) const;
+                const EpilogueParams& epi, be::stream_t s, Profiler* prof = nullptr,
+                long row0 = 0, long nrows = -1) const;
+  // rows per tile of the last-axis passes and whether a launch needs whole tiles
+  int rows_tile() const { return fx_rows ? gx_rows.T : g_rows.T; }
+  bool rows_need_full_tiles() const { return fx_rows; }
   // fused c2r + pointwise + r2c (even d2 only, see can_fuse_rows()); in place on
   // (data, nyq); epi.mode is DIVIDE, UPDATE or STORE
   bool can_fuse_rows() const { return L.even; }
@@ -127,8 +135,10 @@ class Plan3D {
   // strided passes on the main array and its Nyquist plane; mode = MvnStridedMode
   // `s_nyq` (default: s) is the stream of the small Nyquist-plane launches; giving them their own
   // stream lets the 2 MB plane ride along with the full-volume passes (see SideStream)
+  // `z0` / `nz` (default: all d0 planes) restrict the pass to a range of planes (lines along d1
+  // never leave their plane)
   void axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr,
-             be::stream_t s_nyq = nullptr) const;
+             be::stream_t s_nyq = nullptr, int z0 = 0, int nz = -1) const;
   // `src` / `src_nyq` (optional) make the pass out of place: read there, write to data / nyq
   void axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec, const cfloat* spec_nyq,
              be::stream_t s, Profiler* prof = nullptr, be::stream_t s_nyq = nullptr,
@@ -227,6 +237,22 @@ class Engine {
   // w_v (next_v - psi), computed from the current psi without changing it
   void compute_delta(double lambda, float min_value);
   void apply_delta();
+  // The same step in pieces, so that the caller's all-reduce can run under the compute
+  // ("overlap ... by chunking along dim0").  The correction is produced by the LAST
+  // pass of the last local view and consumed by passes that never leave a dim0 plane (psi += delta,
+  // forward last-axis and dim1 passes of the next iteration), so both ends can go chunk by chunk:
+  //   n = delta_chunks(wanted)
+  //   compute_delta_head(lambda, min)            all passes but the last view's final one
+  //   for c < n: compute_delta_chunk(c, n)       planes [c d0/n, (c+1) d0/n) of delta are final;
+  //                                              the caller starts that chunk's all-reduce
+  //   for c < n: [wait for chunk c's collective] apply_delta_chunk(c, n, feed_next)
+  // feed_next != 0 additionally leaves the chunk's part of psi's dim1-transformed spectrum for the
+  // next compute_delta_head (which then skips those two shared passes).
+  int delta_chunks(int wanted) const;
+  void delta_chunk_range(int c, int n, size_t* first_float, size_t* n_floats) const;
+  void compute_delta_head(double lambda, float min_value);
+  void compute_delta_chunk(int c, int n);
+  void apply_delta_chunk(int c, int n, bool feed_next);
   float* delta_ptr();
   // use caller-owned device memory (volume_floats() floats) as the delta buffer, so that a
   // collective library can all-reduce it in place; nullptr returns to an engine-owned buffer
@@ -240,6 +266,7 @@ class Engine {
     pipelined_ = false;
     quotient_guard_ = false;
     work_has_psi_spectrum_ = false;
+    psi_spec_valid_ = false;
   }
   void sync();
   // PSF spectra re-used / prepared since process start (all engines)
@@ -275,6 +302,13 @@ class Engine {
   float* psi_spec_ = nullptr;
   cfloat* psi_spec_nyq_ = nullptr;
   bool work_has_psi_spectrum_ = false;  // work_ holds the last-axis transform of the current psi
+  bool psi_spec_valid_ = false;         // psi_spec_ holds the last-axis + dim1 transform of the current psi
+  // chunked simultaneous step: the last local view's final pass, parked by compute_delta_head
+  EpilogueParams tail_epi_;
+  bool tail_pending_ = false;
+  int fed_n_ = 0, fed_ = 0;  // apply_delta_chunk(.., feed_next): chunks of the current round fed so far
+  Profiler* tail_prof_ = nullptr;
+  void chunk_planes(int c, int n, int* z0, int* nz) const;
   bool quotient_guard_ = false;
   long pair_counter_ = 0;
   // one steady-state sweep over all views captured as a graph (small, launch-bound volumes);

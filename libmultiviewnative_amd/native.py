@@ -33,6 +33,8 @@ ENGINE_ABI_SYMBOLS = [
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
     "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
+    "mvn_engine_delta_chunks", "mvn_engine_delta_chunk_range", "mvn_engine_compute_delta_head",
+    "mvn_engine_compute_delta_chunk", "mvn_engine_apply_delta_chunk",
     "mvn_engine_bind_delta", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
     "mvn_engine_profile", "mvn_engine_profile_read", "mvn_kernel_kind_count",
     "mvn_kernel_kind_name", "mvn_engine_B",
@@ -106,6 +108,12 @@ class Binding:
         l.mvn_engine_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_float]
         l.mvn_engine_compute_delta.argtypes = [C.c_void_p, C.c_double, C.c_float]
         l.mvn_engine_apply_delta.argtypes = [C.c_void_p]
+        l.mvn_engine_delta_chunks.argtypes = [C.c_void_p, C.c_int]
+        l.mvn_engine_delta_chunk_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t),
+                                                   C.POINTER(C.c_size_t)]
+        l.mvn_engine_compute_delta_head.argtypes = [C.c_void_p, C.c_double, C.c_float]
+        l.mvn_engine_compute_delta_chunk.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.mvn_engine_apply_delta_chunk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         l.mvn_engine_delta_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.mvn_engine_psi_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.mvn_engine_bind_delta.argtypes = [C.c_void_p, C.c_void_p]
@@ -303,6 +311,24 @@ class EngineHandle:
 
     def apply_delta(self):
         self.b.check(self.b.l.mvn_engine_apply_delta(self.h))
+
+    # the same step in pieces (all-reduce under compute): see include/mvn_engine_api.h
+    def delta_chunks(self, wanted):
+        return self.b.check(self.b.l.mvn_engine_delta_chunks(self.h, int(wanted)))
+
+    def delta_chunk_range(self, c, n):
+        a, cnt = C.c_size_t(), C.c_size_t()
+        self.b.check(self.b.l.mvn_engine_delta_chunk_range(self.h, c, n, C.byref(a), C.byref(cnt)))
+        return a.value, cnt.value
+
+    def compute_delta_head(self, lambda_, min_value):
+        self.b.check(self.b.l.mvn_engine_compute_delta_head(self.h, lambda_, min_value))
+
+    def compute_delta_chunk(self, c, n):
+        self.b.check(self.b.l.mvn_engine_compute_delta_chunk(self.h, c, n))
+
+    def apply_delta_chunk(self, c, n, feed_next):
+        self.b.check(self.b.l.mvn_engine_apply_delta_chunk(self.h, c, n, 1 if feed_next else 0))
 
     def _ptr(self, fn):
         p, n = C.c_void_p(), C.c_size_t()

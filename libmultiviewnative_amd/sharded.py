@@ -2,12 +2,19 @@
 per-view correction per iteration (the reference has no multi-GPU code).
 
 Every rank holds a replica of psi and the stacks of its own views.  Per iteration each rank
-computes, from the same psi_k, ``delta = sum_{v in my views} w_v (next_v - psi_k)`` on its GPU
-(``mvn_engine_compute_delta``), the deltas are summed over ranks with ONE all-reduce
+computes, from the same psi_k, ``delta = sum_{v in my views} w_v (next_v - psi_k)`` on its GPU,
+the deltas are summed over ranks with ONE all-reduce of the psi-sized buffer
 (``torch.distributed``: backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests), and
 ``psi_{k+1} = psi_k + delta`` is applied on every rank.  For a single view this equals the
 reference's sequential sweep; for several views it is its Jacobi counterpart, and the parity
 oracle is the CPU restatement run in the same mode.
+
+The all-reduce is issued in CHUNKS of dim0 planes and runs under the compute: the correction
+leaves the last pass of the last local view chunk by chunk (``compute_delta_chunk``), each
+chunk's collective starts as soon as its kernel has been enqueued, and ``psi += delta`` plus the
+next iteration's forward last-axis and dim1 passes (all local to a dim0 plane) follow chunk by
+chunk behind the collectives that have completed (``apply_delta_chunk``).  What stays exposed is
+the all-reduce of the first chunks minus the compute it overlaps with.
 """
 
 
@@ -20,32 +27,93 @@ def view_partition(num_views, world_size, rank):
     return list(range(begin, begin + base + (1 if rank < rem else 0)))
 
 
-class SimultaneousDriver:
-    """Runs the sharded iteration loop on any engine-like object.
+class _Ordering:
+    """How a collective on a buffer the engine writes / reads is ordered against the engine's own
+    HIP stream.
 
-    `engine` needs ``compute_delta(lambda, min_value)``, ``apply_delta()`` and ``sync()``;
-    `delta` is the torch tensor aliasing the engine's delta buffer (device memory for the HIP
-    engine); `dist` is ``torch.distributed`` (or None for a single rank).
+    * ``stream`` given (a ``torch.cuda.ExternalStream`` wrapping ``engine.stream()``): collectives
+      are issued with that stream current, so the communication library's stream waits for the
+      engine work enqueued so far, and ``work.wait()`` makes the engine stream wait for the
+      collective -- no host synchronisation anywhere, compute keeps being enqueued meanwhile.
+    * no stream: host-synchronised fallback, valid for every backend and for host tensors: the
+      engine is drained before the collective reads the buffer and the collective is complete
+      (``work.wait()`` plus, for device tensors, a synchronise of torch's current stream) before
+      the engine touches it again.
     """
 
-    def __init__(self, engine, delta, dist=None, after_collective=None):
+    def __init__(self, engine, stream=None, after_collective=None):
+        self.engine = engine
+        self.stream = stream
+        self.after_collective = after_collective
+
+    def _ctx(self):
+        import contextlib
+        if self.stream is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.stream)
+
+    def start(self, issue):
+        """`issue()` starts the collective with async_op=True and returns its work handle."""
+        if self.stream is None:
+            self.engine.sync()  # the buffer must be complete before the collective reads it
+        with self._ctx():
+            return issue()
+
+    def finish(self, work, tensor):
+        with self._ctx():
+            if work is not None:
+                work.wait()
+            if self.stream is None and getattr(tensor, "is_cuda", False):
+                import torch
+                torch.cuda.current_stream(tensor.device).synchronize()
+        if self.after_collective is not None:
+            self.after_collective()
+
+
+class SimultaneousDriver:
+    """Runs the sharded iteration loop on an engine (``native.EngineHandle`` or anything with
+    ``compute_delta_head / compute_delta_chunk / apply_delta_chunk / delta_chunks /
+    delta_chunk_range / sync``).
+
+    `delta` is the torch tensor aliasing the engine's delta buffer (device memory for the HIP
+    engine, bound with ``bind_delta``); `dist` is ``torch.distributed`` (None: single rank);
+    `chunks` the wanted number of dim0 chunks (the engine may allow fewer); `stream` see
+    :class:`_Ordering`.
+    """
+
+    def __init__(self, engine, delta, dist=None, after_collective=None, chunks=4, stream=None):
         self.engine = engine
         self.delta = delta
         self.dist = dist
-        self.after_collective = after_collective
+        self.order = _Ordering(engine, stream, after_collective)
+        self.multi = dist is not None and dist.get_world_size() > 1
+        self.n = engine.delta_chunks(chunks if self.multi else 1)
+        self.parts = []
+        if self.multi:
+            flat = delta.view(-1)
+            for c in range(self.n):
+                first, count = engine.delta_chunk_range(c, self.n)
+                self.parts.append(flat[first:first + count])
 
-    def step(self, lambda_, min_value):
-        self.engine.compute_delta(lambda_, min_value)
-        if self.dist is not None and self.dist.get_world_size() > 1:
-            self.engine.sync()  # the delta must be complete before the collective reads it
-            self.dist.all_reduce(self.delta, op=self.dist.ReduceOp.SUM)
-            if self.after_collective is not None:
-                self.after_collective()  # e.g. torch.cuda.current_stream().synchronize()
-        self.engine.apply_delta()
+    def step(self, lambda_, min_value, feed_next=False):
+        eng, n = self.engine, self.n
+        eng.compute_delta_head(lambda_, min_value)
+        works = []
+        for c in range(n):
+            eng.compute_delta_chunk(c, n)
+            if self.multi:
+                part = self.parts[c]
+                works.append(self.order.start(
+                    lambda: self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, async_op=True)))
+        for c in range(n):
+            if self.multi:
+                self.order.finish(works[c], self.parts[c])
+            eng.apply_delta_chunk(c, n, feed_next)
 
     def run(self, iterations, lambda_, min_value):
-        for _ in range(iterations):
-            self.step(lambda_, min_value)
+        for it in range(iterations):
+            self.step(lambda_, min_value, feed_next=it + 1 < iterations)
         self.engine.sync()
 
 
@@ -56,22 +124,24 @@ class SlabDriver:
 
     `engine` is a ``native.SlabHandle`` (or anything with pack / mid / unpack / sync);
     `a_main, b_main, a_nyq, b_nyq` are torch tensors aliasing its exchange buffers (``a_nyq`` /
-    ``b_nyq`` may be None for odd d2); `dist` is ``torch.distributed``.
+    ``b_nyq`` may be None for odd d2); `dist` is ``torch.distributed``; `stream` see
+    :class:`_Ordering`.
     """
 
-    def __init__(self, engine, a_main, b_main, a_nyq, b_nyq, dist, after_collective=None):
+    def __init__(self, engine, a_main, b_main, a_nyq, b_nyq, dist, after_collective=None, stream=None):
         self.engine = engine
         self.a_main, self.b_main, self.a_nyq, self.b_nyq = a_main, b_main, a_nyq, b_nyq
         self.dist = dist
-        self.after_collective = after_collective
+        self.order = _Ordering(engine, stream, after_collective)
 
     def _exchange(self, src_main, dst_main, src_nyq, dst_nyq):
-        self.engine.sync()  # the buffers must be complete before the collective reads them
-        self.dist.all_to_all_single(dst_main, src_main)
+        w1 = self.order.start(lambda: self.dist.all_to_all_single(dst_main, src_main, async_op=True))
+        w2 = None
         if src_nyq is not None:
-            self.dist.all_to_all_single(dst_nyq, src_nyq)
-        if self.after_collective is not None:
-            self.after_collective()
+            w2 = self.order.start(lambda: self.dist.all_to_all_single(dst_nyq, src_nyq, async_op=True))
+        self.order.finish(w1, dst_main)
+        if w2 is not None:
+            self.order.finish(w2, dst_nyq)
 
     def view_update(self, v, lambda_, min_value, feed_next):
         for conv in (0, 1):

@@ -1,6 +1,7 @@
-"""world_size-2 gloo run of the view-sharded driver on CPU: the product's partition + loop
-(libmultiviewnative_amd/sharded.py) around an oracle-backed engine must reproduce the oracle's
-single-process simultaneous mode.  (On the GPU the same driver wraps the HIP engine.)"""
+"""world_size-2 gloo runs of the multi-GPU drivers on CPU: the product's partition + loop
+(libmultiviewnative_amd/sharded.py) around the PRODUCT engine on its host-emulation backend must
+reproduce the oracle's single-process simultaneous mode (view sharding) and sequential sweep
+(slab decomposition).  On the GPU the same drivers wrap the HIP engine."""
 import os
 import socket
 import sys
@@ -28,63 +29,94 @@ def test_view_partition():
         view_partition(4, 2, 2)
 
 
-class OracleShardEngine:
-    """Engine-like test double: the oracle computes this rank's partial correction."""
-
-    def __init__(self, psi, holder, my_views):
-        from oracle import binding as orc
-        self.orc = orc
-        self.psi = psi.copy()
-        self.holder = holder
-        self.my = my_views
-        self.delta = torch.zeros(psi.shape, dtype=torch.float32)
-
-    def compute_delta(self, lam, minv):
-        d = np.zeros_like(self.psi)
-        if self.my:
-            d = self.orc.simultaneous_step(self.psi, self.holder, self.my[0], self.my[-1] + 1, 1)
-        self.delta.copy_(torch.from_numpy(d))
-
-    def apply_delta(self):
-        self.psi = self.psi + self.delta.numpy()
-
-    def sync(self):
-        pass
+# (shape, views, world): 3 views split 2 + 1 (generic kernels, odd d2 = padded rows), a
+# fixed-kernel shape (whole-tile chunks), and 1 view on 2 ranks (rank 1 has none and contributes zeros)
+SIM_CASES = {"split21": ((12, 10, 14), 3, 2), "odd": ((8, 6, 9), 3, 2), "fixed": ((64, 64, 32), 2, 2),
+             "idle_rank": ((12, 10, 14), 1, 2)}
+SIM_ITS = 3
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, case):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
+    from libmultiviewnative_amd import native
     from ref_fixtures import realistic_views
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    shape = (12, 10, 14)
-    _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (3, 3, 3))
-    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
-    eng = OracleShardEngine(psi0, h, view_partition(3, world, rank))
-    SimultaneousDriver(eng, eng.delta, dist).run(3, 0.006, 1e-4)
-    np.save(os.path.join(out_dir, "psi_rank%d.npy" % rank), eng.psi)
+    shape, V, _ = SIM_CASES[case]
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (3, 3, 3))
+    mine = view_partition(V, world, rank)
+    # the PRODUCT engine (compute_delta_head / _chunk / apply_delta_chunk, bind_delta) on the
+    # host-emulation backend, driven by the product's SimultaneousDriver
+    emu = native.Binding(native.EMU_SO)
+    eng = emu.engine(shape, len(mine))
+    for i, v in enumerate(mine):
+        eng.set_view(i, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    delta = torch.zeros(eng.psi_ptr()[1], dtype=torch.float32)
+    eng.bind_delta(delta.data_ptr())
+    drv = SimultaneousDriver(eng, delta, dist, chunks=3)
+    assert drv.n >= 2
+    drv.run(SIM_ITS, 0.006, 1e-4)
+    np.save(os.path.join(out_dir, "psi_rank%d.npy" % rank), eng.get_psi())
+    eng.bind_delta(None)
+    eng.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("case", sorted(SIM_CASES))
+def test_two_rank_gloo_matches_single_process(tmp_path, case):
     from oracle import binding as orc
     from ref_fixtures import realistic_views
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    shape, V, world = SIM_CASES[case]
+    mp.spawn(_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
     a = np.load(tmp_path / "psi_rank0.npy")
     b = np.load(tmp_path / "psi_rank1.npy")
     assert np.array_equal(a, b)  # replicas stay identical
-    shape = (12, 10, 14)
-    _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (3, 3, 3))
-    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (3, 3, 3))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, SIM_ITS)
     ref = orc.cpu_deconvolve_simultaneous(psi0, h, 1)
-    assert np.abs(a - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert np.abs(a - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_chunked_step_equals_whole_step():
+    """compute_delta_head + chunks + apply_delta_chunk(feed_next) must give bit for bit what
+    compute_delta + apply_delta give (same kernels on row / plane ranges)."""
+    from libmultiviewnative_amd import native
+    from ref_fixtures import realistic_views
+    emu = native.Binding(native.EMU_SO)
+    for shape in ((12, 10, 14), (64, 32, 32), (6, 5, 9)):
+        _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (3, 3, 3), seed=5)
+        outs = []
+        for chunked in (False, True):
+            e = emu.engine(shape, 2)
+            for v in range(2):
+                e.set_view(v, views[v], w[v], k1[v], k2[v])
+            e.set_psi(psi0)
+            if chunked:
+                n = e.delta_chunks(4)
+                assert n >= 2
+                for it in range(3):
+                    e.compute_delta_head(0.006, 1e-4)
+                    for c in range(n):
+                        e.compute_delta_chunk(c, n)
+                    for c in reversed(range(n)):  # any order within a round
+                        e.apply_delta_chunk(c, n, it < 2)
+            else:
+                for it in range(3):
+                    e.compute_delta(0.006, 1e-4)
+                    e.apply_delta()
+            e.sync()
+            outs.append(e.get_psi())
+            e.close()
+        assert np.array_equal(outs[0], outs[1])
 
 
 # ---- slab-decomposed sequential sweep (SURVEY.md 8e row 3) -------------------------------------

@@ -1,29 +1,46 @@
 #!/usr/bin/env python3
 """Headline benchmark: multi-view Richardson-Lucy iterations/s on 512^3 float32, 6 views.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4]
 
-A "step" is one RL iteration = one sweep over all views resident on a GPU (BASELINE.json
-configs[2]: 512^3 f32, 6 views, 31^3 PSFs), with every stack, both PSF spectra per view and psi
-already resident in HBM when the timed region starts.
+A "step" is one RL iteration = one update of psi from ALL views of ONE problem (BASELINE.json
+configs[2] by default: 512^3 f32, 6 views, 31^3 PSFs), with every stack, both PSF spectra per
+view and psi resident in HBM when the timed region starts.  `value` = iterations/s of the whole
+problem at every N -> strong scaling.
 
 N = 1   the reference's sequential (Gauss-Seidel) view sweep (src/gpu_deconvolve_methods.cuh:
-        487-535) through the C-ABI engine of lib/libmultiviewnative.so.
-N > 1   one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI); every rank
-        holds 6 views of a 6N-view data set and a replica of psi; per iteration each rank
-        computes its correction sum from the same psi and ONE all-reduce of the 512^3 float32
-        delta combines them (simultaneous update).  Per-GPU work is fixed -> weak
-        scaling; `value` counts 6-view sweeps per second over all ranks.
+        487-535) through the C-ABI engine of lib/libmultiviewnative.so -- the headline number.
+N > 1   one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The views of
+        the SAME problem are partitioned over the ranks (6 views: 3+3, 2+2+1+1, and at N = 8 six
+        ranks with one view each plus two that only hold a replica of psi); every rank computes
+        the correction of its views from the same psi and ONE all-reduce of the psi-sized delta
+        per iteration combines them (simultaneous / Jacobi update), issued in
+        dim0 chunks under the compute (libmultiviewnative_amd/sharded.py).
+        `python bench.py --gpus N` starts its N ranks itself (children are spawned before the
+        parent touches the GPU); under `python -m torch.distributed.run ... bench.py --gpus N`
+        it is one of the ranks.
 
-Rank 0 prints ONE JSON line (the driver's contract) with two extra objects:
+--config 1  256^3, 1 view, 15^3 PSF            (BASELINE.json configs[1])
+--config 2  512^3, 6 views, 31^3 PSFs          (configs[2], default, the metric's configuration)
+--config 3  512^3, 8 views (1 per GPU at N=8)  (configs[3])
+--config 4  320x1920x1920, 6 views, 31^3 PSFs  (configs[4]; 2+2+1+1 at N=4)
+
+Rank 0 prints ONE JSON line (the driver's contract) with extra objects:
   roofline      dominant kernel: algorithmic bytes per launch / average launch duration (HIP
                 events on the engine's stream, taken inside the timed region) vs 8 TB/s HBM
   cpu_baseline  the oracle (CPU restatement of inplace_cpu_deconvolve) timed on this host on a
-                bounded sample (N = 1, rank 0 only)
+                bounded sample: ONE view update of the timed problem, started from the psi the
+                timed region left (rank 0 only)
+  parity        that same view update through the product's reference entry point
+                (inplace_gpu_deconvolve, host buffers) compared with the oracle's result
+  abi_end_to_end  one inplace_gpu_deconvolve call with host buffers (what the reference's
+                bench/bench_gpu_deconvolve_synthetic.cu:190-203 times), PCIe included; never `value`
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +49,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+LAMBDA, MIN_VALUE = 0.006, 1e-4  # Fiji defaults (tests/tiff_fixtures.hpp:449-450)
+
+CONFIGS = {
+    1: dict(size=[256, 256, 256], views=1, psf=15),
+    2: dict(size=[512, 512, 512], views=6, psf=31),
+    3: dict(size=[512, 512, 512], views=8, psf=31),
+    4: dict(size=[320, 1920, 1920], views=6, psf=31),
+}
 
 
 def gaussian_psf(edge, sigma):
@@ -42,14 +67,30 @@ def gaussian_psf(edge, sigma):
     return (g / g.sum()).astype(np.float32)
 
 
+def make_view(shape, v, psf_edge):
+    """View v of the synthetic problem: the same on every rank and in every leg of the bench."""
+    import numpy as np
+    rng = np.random.default_rng(1000 + v)
+    view = rng.random(shape, dtype=np.float32) * 50 + 10
+    sig = [2.0, 2.0, 2.0]
+    sig[v % 3] = 4.0
+    edge = min(psf_edge, *shape)
+    psf = gaussian_psf(edge, sig)
+    return view, psf, np.ascontiguousarray(psf[::-1, ::-1, ::-1])
+
+
+def start_value():
+    return 35.0  # the views are uniform in [10, 60)
+
+
 def kernel_bytes(kind, d0, d1, d2):
-    """Algorithmic HBM bytes of ONE launch of each kernel kind (DESIGN.md section 5)."""
+    """Algorithmic HBM bytes of ONE launch of each kernel kind (DESIGN.md section 4)."""
     vol = 4.0 * d0 * d1 * d2            # dense real volume == main half-spectrum array
     nyq = 8.0 * d0 * d1 if d2 % 2 == 0 else 0.0
     B = vol + nyq                       # the reference's in-place r2c footprint (SURVEY.md 8d)
     return {
         "rows_r2c": vol + B,            # read real volume, write half-spectrum (+ Nyquist plane)
-        "rows_c2r": B + 2.5 * vol,      # read spectrum, write volume; + view (divide) or psi+weights (update): mean 1.5
+        "rows_c2r": B + 3 * vol,        # read spectrum, psi, weights; write delta (un-chunked DELTA pass)
         # c2r + pointwise + r2c in one pass: read spectrum, write spectrum, + view (divide) or
         # psi + weights in, psi out (update)
         "rows_fused_div": 2 * B + vol,
@@ -63,46 +104,98 @@ def kernel_bytes(kind, d0, d1, d2):
     }.get(kind, 0.0), B
 
 
-def cpu_baseline(shape, psf_edge, n_views):
-    """Time the CPU oracle on a bounded sample: 1 of the views, 1 iteration, all host cores; the
-    per-iteration figure for `n_views` views follows by scaling (the loop is linear in views)."""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as children of this
+    process, which itself never touches the GPU (no HIP / torch.cuda call before or after), let
+    rank 0's JSON line through on stdout and leave with the children's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
+    cmd += sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def one_view_check(lib, shape, psf_edge, n_views, psi_t, device, want_cpu):
+    """ONE view update (view 0 of the timed problem, one iteration) started from the psi the timed
+    region left: through the product's reference entry point on host buffers, and -- timed -- through
+    the CPU oracle.  Gives the parity figures and the bounded CPU baseline sample in one go."""
     import numpy as np
     from libmultiviewnative_amd.abi import WorkspaceHolder
+    view, k1, k2 = make_view(shape, 0, psf_edge)
+    w = np.full(shape, 1.0 / n_views, np.float32)
+    h = WorkspaceHolder([view], [k1], [k2], [w], LAMBDA, MIN_VALUE, 1)
+    lib.set_pad_mode("none")  # the CPU path's policy (cyclic on image_dims_): the parity target
+    got = lib.gpu_deconvolve(psi_t, h, device)
+    lib.set_pad_mode(None)
+    lib.check(lib.l.mvn_release_cached_engines())
+    out = {"gpu_checksum": float(got.astype(np.float64).sum())}
+    if not want_cpu:
+        return out, None
     from oracle import binding as orc
-    rng = np.random.default_rng(1)
-    view = rng.random(shape, dtype=np.float32) * 50 + 10
-    psf = gaussian_psf(psf_edge, (3.0, 2.0, 2.0))
-    h = WorkspaceHolder([view], [psf], [np.ascontiguousarray(psf[::-1, ::-1, ::-1])],
-                        [np.ones(shape, np.float32)], 0.006, 1e-4, 1)
-    psi0 = np.full(shape, np.float32(view.mean()), np.float32)
     cores = orc.threads(-1)
-    orc.cpu_deconvolve(psi0, h, -1)
+    ref = orc.cpu_deconvolve(psi_t, h, -1)
     setup_s, loop_s = orc.last_timing()
-    return {
+    d = got.astype(np.float64) - ref.astype(np.float64)
+    out.update({
+        "case": "view 0 of the timed problem, 1 iteration from the timed psi: inplace_gpu_deconvolve (host "
+                "buffers, cyclic policy) vs CPU oracle",
+        "oracle_checksum": float(ref.astype(np.float64).sum()),
+        "max_rel": float(np.abs(d).max() / np.abs(ref).max()),
+        "rms_rel": float(np.sqrt((d * d).mean()) / np.sqrt((ref.astype(np.float64) ** 2).mean())),
+        "tolerance": {"max_rel": 1e-4, "rms_rel": 1e-5},
+    })
+    out["ok"] = bool(out["max_rel"] <= 1e-4 and out["rms_rel"] <= 1e-5)
+    cpu = {
         "value": 1.0 / (loop_s * n_views),
         "unit": "RL iterations/s (%d views)" % n_views,
         "cores": cores,
-        "kind": "port",
-        "sample": "%dx%dx%d f32, 1 of %d views, 1 iteration (loop %.2f s, PSF setup %.2f s excluded), "
-                  "scaled x1/%d" % (shape[0], shape[1], shape[2], n_views, loop_s, setup_s, n_views),
+        "kind": orc.fft_backend(),  # "port" (the oracle's own FFT) or "fftw" (dlopen'ed libfftw3f, the reference's)
+        "sample": "%dx%dx%d f32, view 0 of %d, 1 iteration from the timed psi (loop %.2f s, PSF setup %.2f s "
+                  "excluded), scaled x1/%d" % (shape[0], shape[1], shape[2], n_views, loop_s, setup_s, n_views),
     }
+    if cpu["kind"] == "port":
+        cpu["note"] = "libfftw3f.so.3 not found on this host: the port's own mixed-radix FFT is not FFTW"
+    return out, cpu
 
 
-def small_parity(lib):
-    """GPU vs CPU oracle on a small realistic case, reported beside the timing."""
+def abi_end_to_end(lib, shape, psf_edge, n_views, iterations, device, pad_mode):
+    """inplace_gpu_deconvolve with host buffers, as Fiji calls it and as the reference's
+    bench_gpu_deconvolve_synthetic times it: uploads, PSF preparation, loop, download."""
     import numpy as np
     from libmultiviewnative_amd.abi import WorkspaceHolder
-    from oracle import binding as orc
-    from ref_fixtures import realistic_views
-    shape = (64, 64, 64)
-    _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (9, 9, 9))
-    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 5)
-    got = lib.gpu_deconvolve(psi0, h, 0).astype(np.float64)
-    ref = orc.cpu_deconvolve(psi0, h, -1).astype(np.float64)
-    d = got - ref
-    return {"case": "64^3, 3 views, 9^3 PSF, 5 it vs CPU oracle",
-            "max_rel": float(np.abs(d).max() / np.abs(ref).max()),
-            "rms_rel": float(np.sqrt((d * d).mean()) / np.sqrt((ref * ref).mean()))}
+    views, k1s, k2s = [], [], []
+    for v in range(n_views):
+        view, k1, k2 = make_view(shape, v, psf_edge)
+        views.append(view)
+        k1s.append(k1)
+        k2s.append(k2)
+    w = np.full(shape, 1.0 / n_views, np.float32)
+    h = WorkspaceHolder(views, k1s, k2s, [w] * n_views, LAMBDA, MIN_VALUE, iterations)
+    psi0 = np.full(shape, np.float32(start_value()), np.float32)
+    lib.set_pad_mode(pad_mode)
+    secs = []
+    ok = True
+    for _ in range(3):
+        t = time.perf_counter()
+        out = lib.gpu_deconvolve(psi0, h, device)
+        secs.append(time.perf_counter() - t)
+        ok = ok and bool(np.isfinite(out).all() and not np.array_equal(out, psi0))
+    lib.set_pad_mode(None)
+    lib.check(lib.l.mvn_release_cached_engines())
+    warm = min(secs[1:])
+    return {"pad_mode": pad_mode, "iterations": iterations, "seconds_first_call": round(secs[0], 4),
+            "seconds_warm_call": round(warm, 4), "iterations_per_s_warm": round(iterations / warm, 3),
+            "result_finite_and_changed": ok}
 
 
 def main():
@@ -110,34 +203,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
-    ap.add_argument("--views-per-gpu", type=int, default=6)
-    ap.add_argument("--psf", type=int, default=31)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
-                    help="BASELINE.json configs[i]: 1 = 256^3 x 1 view x 15^3 PSF, 2 = 512^3 x 6 views x 31^3 "
-                         "(default, the headline), 4 = 320x1920x1920 x 6 views x 31^3")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[i] (see the module docstring); default 2, the headline")
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="override the volume (test rehearsals)")
+    ap.add_argument("--views", type=int, default=None, help="override the TOTAL number of views")
+    ap.add_argument("--psf", type=int, default=None, help="override the PSF edge")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel events in the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1,
                     help="rehearsal on a one-GPU box: put every rank on this device (needs --backend gloo)")
     ap.add_argument("--simultaneous", action="store_true",
-                    help="run the simultaneous-update (Jacobi) loop even on one rank (what every rank of an N>1 run computes)")
+                    help="run the simultaneous-update (Jacobi) loop even on one rank (what the ranks of an N>1 run compute)")
+    ap.add_argument("--chunks", type=int, default=4, help="dim0 chunks of the overlapped all-reduce (N > 1)")
+    ap.add_argument("--host-sync", action="store_true",
+                    help="N > 1: order collectives against the engine with host synchronisation instead of stream events")
     ap.add_argument("--no-side", action="store_true",
-                    help="skip ms_per_fft and the small parity case (keeps rocprof --stats averages clean)")
+                    help="skip ms_per_fft, the one-view parity check and the ABI end-to-end call "
+                         "(keeps rocprof --stats averages clean)")
+    ap.add_argument("--no-abi", action="store_true", help="skip the ABI end-to-end call")
+    ap.add_argument("--dump-psi", default=None, help="rank 0 saves the final psi here (.npy)")
     args = ap.parse_args()
 
-    if args.config == 1:
-        args.size, args.views_per_gpu, args.psf = [256, 256, 256], 1, 15
-    elif args.config == 4:
-        args.size, args.views_per_gpu, args.psf = [320, 1920, 1920], 6, 31
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(args))  # the parent never touches the GPU
+
+    cfg = CONFIGS[args.config]
+    shape = tuple(args.size or cfg["size"])
+    V = args.views if args.views is not None else cfg["views"]
+    psf_edge = args.psf or cfg["psf"]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+    world = int(world_env or "1")
+    args.gpus = world
 
     dist = None
     torch = None
@@ -155,41 +254,36 @@ def main():
 
     import numpy as np
     from libmultiviewnative_amd import native
-    from libmultiviewnative_amd.sharded import SimultaneousDriver
+    from libmultiviewnative_amd.sharded import SimultaneousDriver, view_partition
 
     lib = native.lib()  # raises if the HIP library is missing: there is no fallback
-    shape = tuple(args.size)
-    V = args.views_per_gpu
-    lam, minv = 0.006, 1e-4  # Fiji defaults (tests/tiff_fixtures.hpp:449-450)
-
-    eng = lib.engine(shape, V, device=local_rank)
-    rng = np.random.default_rng(1000 + rank)
-    weights = np.full(shape, 1.0 / (V * world), np.float32)
-    mean = 35.0  # the views are uniform in [10, 60); the same start value on every rank keeps the replicas identical
-    for v in range(V):
-        view = rng.random(shape, dtype=np.float32) * 50 + 10
-        sig = [2.0, 2.0, 2.0]
-        sig[v % 3] = 4.0
-        psf = gaussian_psf(args.psf, sig)
-        eng.set_view(v, view, weights, psf, np.ascontiguousarray(psf[::-1, ::-1, ::-1]))
+    mine = view_partition(V, world, rank)
+    eng = lib.engine(shape, len(mine), device=local_rank)
+    weights = np.full(shape, 1.0 / V, np.float32)
+    for i, v in enumerate(mine):
+        view, k1, k2 = make_view(shape, v, psf_edge)
+        eng.set_view(i, view, weights, k1, k2)
         del view
-    eng.set_psi(np.full(shape, np.float32(mean), np.float32))
+    del weights
+    eng.set_psi(np.full(shape, np.float32(start_value()), np.float32))
 
     driver = None
+    delta = None
     if world > 1:
         nfl = eng.psi_ptr()[1]
-        delta = torch.zeros(nfl, dtype=torch.float32, device="cuda:%d" % local_rank)
+        dev = torch.device("cuda", local_rank)
+        delta = torch.zeros(nfl, dtype=torch.float32, device=dev)
         eng.bind_delta(delta.data_ptr())
-        driver = SimultaneousDriver(eng, delta, dist,
-                                    after_collective=lambda: torch.cuda.current_stream().synchronize())
+        ext = None if args.host_sync else torch.cuda.ExternalStream(eng.stream(), device=dev)
+        driver = SimultaneousDriver(eng, delta, dist, chunks=args.chunks, stream=ext)
     elif args.simultaneous:
         driver = SimultaneousDriver(eng, None, None)
 
     def run(steps):
         if driver is None:
-            eng.iterate(steps, lam, minv, sync=True)
+            eng.iterate(steps, LAMBDA, MIN_VALUE, sync=True)
         else:
-            driver.run(steps, lam, minv)
+            driver.run(steps, LAMBDA, MIN_VALUE)
 
     def fence():
         eng.sync()
@@ -203,7 +297,9 @@ def main():
         dist.all_reduce(delta, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         delta.zero_()
-    run(args.warmup)
+        torch.cuda.synchronize()
+    if args.warmup > 0:
+        run(args.warmup)
     if not args.no_profile:
         # events around the launches of every 5th (view, iteration) of the timed region: enough
         # samples of every kernel, < 1 % perturbation (all launches: 3 %)
@@ -221,16 +317,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    psi = eng.get_psi()
-    psi_ok = bool(np.isfinite(psi).all() and (psi > 0).all())
-
     out = None
+    psi = None
     if rank == 0:
+        psi = eng.get_psi()
+        psi_ok = bool(np.isfinite(psi).all() and (psi > 0).all())
+        if args.dump_psi:
+            np.save(args.dump_psi, psi)
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
+        value = args.steps / elapsed  # iterations/s of the WHOLE problem, at every N
         d0, d1, d2 = shape
+        vol = 4.0 * d0 * d1 * d2
         # dominant kernel by total time inside the timed region
         roofline = None
+        prof = {k: v for k, v in prof.items() if v[1] and kernel_bytes(k, d0, d1, d2)[0] > 0}
         if prof:
             kind = max(prof, key=lambda k: prof[k][0])
             tot_ms, n = prof[kind]
@@ -243,7 +343,7 @@ def main():
                         "bytes_per_launch": kb,
                         "per_kernel": {k: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1],
                                            "GBps": round(kernel_bytes(k, d0, d1, d2)[0] / (v[0] / v[1] * 1e-3) / 1e9, 1)}
-                                       for k, v in prof.items() if v[1]}}
+                                       for k, v in prof.items()}}
             traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(traffic_file) and shape == (512, 512, 512):  # PMC passes were taken at 512^3
                 try:
@@ -252,8 +352,18 @@ def main():
                     pass
         _, B = kernel_bytes("nyquist", d0, d1, d2)
         whole = 25.0 * B * V / (ms_per_step * 1e-3) / 1e9  # 25*B per (view, iteration)
+        parts = [len(view_partition(V, world, r)) for r in range(world)]
+        if driver is None:
+            mode = "sequential (reference order, Gauss-Seidel)"
+        elif world == 1:
+            mode = "simultaneous (Jacobi), single rank"
+        else:
+            mode = "simultaneous (Jacobi): views sharded over ranks + 1 all-reduce of the psi-sized delta per " \
+                   "iteration in %d overlapped chunks (backend %s, %s ordering)" % (
+                       driver.n, args.backend, "host-sync" if args.host_sync else "stream-event")
         out = {
-            "metric": "RL iterations/sec on 512^3 f32, 6 views",
+            "metric": "RL iterations/sec on %s f32, %d views" % (
+                "512^3" if shape == (512, 512, 512) else "%dx%dx%d" % shape, V),
             "value": round(value, 4),
             "unit": "iterations/s",
             "n_gpus": world,
@@ -261,35 +371,51 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%dx%dx%d f32, %d views/GPU, %d^3 PSFs, lambda=0.006" % (d0, d1, d2, V, args.psf),
-                       "views_total": V * world,
-                       "update_mode": "sequential (reference order)" if driver is None else "simultaneous, single rank" if world == 1 else
-                       "simultaneous + 1 all-reduce/iteration (backend %s)" % args.backend,
-                       "unit_of_value": "%d-view sweeps per second over all ranks" % V},
+            "config": {"workload": "BASELINE.json configs[%d]: %dx%dx%d f32, %d views, %d^3 PSFs, lambda=%g, "
+                                   "resident in HBM" % (args.config, d0, d1, d2, V, psf_edge, LAMBDA),
+                       "views_total": V, "views_per_rank": parts,
+                       "update_mode": mode,
+                       "unit_of_value": "updates of psi from all %d views per second (one problem, all ranks)" % V},
             "whole_step_GBps_25B_model": round(whole, 1),
             "whole_step_frac_of_8TBps": round(whole / HBM_PEAK_GBS, 4),
             "psi_finite_positive": psi_ok,
             "roofline": roofline,
         }
+        if driver is None:
+            # what the 8-pass pipeline actually moves: 22 volumes per (view, iteration), DESIGN.md section 4
+            actual = 22.0 * vol * V / (ms_per_step * 1e-3) / 1e9
+            out["whole_step_GBps_actual_22vol"] = round(actual, 1)
+            out["whole_step_actual_frac_of_8TBps"] = round(actual / HBM_PEAK_GBS, 4)
+    if world > 1:
+        eng.bind_delta(None)
     eng.close()
 
-    if rank == 0 and world == 1 and not args.no_side:
+    if rank == 0 and not args.no_side:
         try:
-            out["ms_per_fft"] = round(lib.fft3_time(shape, 0, 10, device=local_rank), 4)
-            out["parity"] = small_parity(lib)
+            if world == 1:
+                out["ms_per_fft"] = round(lib.fft3_time(shape, 0, 10, device=local_rank), 4)
+            parity, cpu = one_view_check(lib, shape, psf_edge, V, psi, local_rank, not args.no_cpu_baseline)
+            out["parity"] = parity
+            if cpu:
+                out["cpu_baseline"] = cpu
+            if world == 1 and not args.no_abi and args.config != 4:
+                its = 10
+                out["abi_end_to_end"] = {
+                    "what": "one inplace_gpu_deconvolve call, %dx%dx%d x %d views x %d iterations, host buffers "
+                            "in and out (PCIe included)" % (shape[0], shape[1], shape[2], V, its),
+                    "cyclic_policy": abi_end_to_end(lib, shape, psf_edge, V, its, local_rank, "none"),
+                }
         except Exception as e:  # the headline number must survive a failing side measurement
-            out["side_measurement_error"] = str(e)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape, args.psf, V)
+            out["side_measurement_error"] = "%s: %s" % (type(e).__name__, e)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -11,14 +11,20 @@
  *  - errors never terminate the host process (the reference calls exit(1) inside the JVM,
  *    inc/cuda_helpers.cuh:17-24): the boundary is noexcept, a diagnostic goes to stderr and
  *    the in/out buffer is left untouched;
- *  - convolution is cyclic on exactly the given dims with the kernel centre on the origin --
- *    the semantics of the reference's CPU path (inc/cpu_convolve.h, no_padd), which is the
- *    parity target; callers pre-pad for linear behaviour as they already do for the CPU path.
- *    The environment variable MVN_PAD_MODE=zero switches inplace_gpu_deconvolve to the reference
- *    GPU entry's zero_padd policy instead (embed in image + kernel - 1, crop on exit;
- *    src/multiviewnative.cu:26-27,128, inc/padd_utils.h:121-138).  With MVN_PAD_GOOD_SIZE=1 on top
- *    the padded extents grow to the next 2^a 3^b 5^c 7^d and the quotient is 0 wherever a view
- *    voxel is exactly 0 (the reference's 0 * 1/0 would be NaN in the added zeros);
+ *  - inplace_gpu_deconvolve follows the reference GPU entry's zero_padd policy
+ *    (src/multiviewnative.cu:26-27,128, inc/padd_utils.h:121-138, src/gpu_deconvolve_methods.cuh:
+ *    366-449,537-549): every stack is embedded in a zero volume of extent >= image + kernel - 1
+ *    at offset (kernel - 1)/2, the loop runs cyclically on that volume and psi is cropped on
+ *    exit -- so a block does not wrap PSF energy across its borders.  Two additions: the padded
+ *    extents grow to FFT-friendly 2^a 3^b 5^c 7^d sizes (542 = 2 * 271 -> 576), and the quotient is
+ *    0 wherever a view voxel is exactly 0 (in the added zeros the reference's 0 * 1/0 would be
+ *    NaN).  mvn_set_pad_mode("zero_exact") (mvn_engine_api.h) or MVN_PAD_MODE=zero_exact keeps
+ *    exactly image + kernel - 1 without the guard; "none" selects the reference CPU path's
+ *    no_padd instead (cyclic on exactly image_dims_, inc/cpu_convolve.h:22-26), which is the
+ *    parity target of the oracle tests;
+ *  - inplace_gpu_convolution and the legacy convolution entry points are cyclic on exactly the
+ *    given dims with the kernel centre on the origin, as in the reference (as_is_padding,
+ *    src/multiviewnative.cu:29-30,39-40,58-75);
  *  - the CPU entry points (inplace_cpu_deconvolve / inplace_cpu_convolution,
  *    inc/multiviewnative.h:43-51) are NOT exported by the product library: this library has
  *    no CPU fallback.  Their restatement lives in oracle/ as test infrastructure.

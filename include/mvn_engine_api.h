@@ -23,6 +23,11 @@ MVN_API const char* mvn_backend_name(void);
 /* inplace_gpu_deconvolve keeps one resident engine per device between calls (same shape and view
  * count are re-used without re-allocating; MVN_ENGINE_CACHE=0 disables it).  This frees them. */
 MVN_API int mvn_release_cached_engines(void);
+/* Padding policy of inplace_gpu_deconvolve for the calls that follow (process-wide): "zero"
+ * (default: the reference GPU entry's zero_padd with FFT-friendly padded extents), "zero_exact"
+ * (exactly image + kernel - 1), "none" (the reference CPU path's cyclic no_padd); NULL or ""
+ * returns to the environment variable MVN_PAD_MODE / the default.  See multiviewnative.h. */
+MVN_API int mvn_set_pad_mode(const char* mode);
 /* A resident engine keeps, per view slot, the PSF spectra of the last call together with host
  * copies of the kernels they were made from; a call (or mvn_engine_set_view) that brings
  * bytewise identical kernels for a slot re-uses the spectra (the reference's

@@ -3,6 +3,7 @@
 // caller's in/out buffers untouched, print one diagnostic to stderr and never terminate the
 // host process (SURVEY.md 8b "Errors").
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 
 #include "../../include/mvn_engine_api.h"
 #include "mvn_engine.hpp"
+#include "mvn_fixed_geom.hpp"
 
 using namespace mvn;
 
@@ -63,6 +65,12 @@ static std::mutex& device_mutex(int device) {
 // block after block of the same shape, and allocating / freeing 4V+2 volumes per call costs more
 // than uploading them.  A call with another shape or view count replaces the
 // cached engine.  MVN_ENGINE_CACHE=0 disables the cache; mvn_release_cached_engines() empties it.
+// The map is process-wide while calls are serialised per DEVICE only (Fiji runs one host thread
+// per GPU), so it has its own mutex, held just around find / erase / insert.
+static std::mutex& engine_cache_mutex() {
+  static std::mutex* m = new std::mutex();
+  return *m;
+}
 static std::map<int, std::unique_ptr<Engine>>& engine_cache() {
   static std::map<int, std::unique_ptr<Engine>>* c = new std::map<int, std::unique_ptr<Engine>>();
   return *c;
@@ -74,23 +82,115 @@ static bool engine_cache_enabled() {
 }
 
 // caller holds device_mutex(dev)
-static std::unique_ptr<Engine> take_engine(int dev, const shape_t& ext, int V) {
+static std::unique_ptr<Engine> pop_cached_engine(int dev) {
+  std::lock_guard<std::mutex> lk(engine_cache_mutex());
   auto& c = engine_cache();
   auto it = c.find(dev);
-  if (it != c.end()) {
-    std::unique_ptr<Engine> e = std::move(it->second);
-    c.erase(it);
-    if (e && engine_cache_enabled()) {
-      const Layout& L = e->layout();
-      if (L.d0 == ext[0] && L.d1 == ext[1] && L.d2 == ext[2] && e->num_views() == V) return e;
-    }
-    e.reset();  // wrong shape: free its memory before the new engine allocates
+  if (it == c.end()) return nullptr;
+  std::unique_ptr<Engine> e = std::move(it->second);
+  c.erase(it);
+  return e;
+}
+
+// caller holds device_mutex(dev).  The memory heuristic of src/multiviewnative.cu:94-119, restated
+// for the resident layout (4 volumes per view -- view, weights, two spectra -- + psi + work, + 2 %
+// slack), is applied only when the call has to allocate: a cached engine of the same shape is
+// re-used as it is (its memory is what the check would ask for), and a stale one of another shape
+// is freed BEFORE the free memory is read.
+static std::unique_ptr<Engine> take_engine(int dev, const shape_t& ext, int V) {
+  std::unique_ptr<Engine> e = pop_cached_engine(dev);
+  if (e && engine_cache_enabled()) {
+    const Layout& L = e->layout();
+    if (L.d0 == ext[0] && L.d1 == ext[1] && L.d2 == ext[2] && e->num_views() == V) return e;
   }
+  e.reset();  // wrong shape: free its memory before the new engine allocates
+  Layout L(ext[0], ext[1], ext[2]);
+  const double need = (4.0 * V + 2.0) * (double)L.B() * 1.02;
+  size_t free_b = 0, total_b = 0;
+  be::device_mem_info(&free_b, &total_b);
+  if (trace_on())
+    std::printf("[lmvn::inplace_gpu_deconvolve] FFT: %.1f MB (all-on-device), available on GPU: %.1f MB ... %s\n",
+                need / 1048576.0, free_b / 1048576.0, need < free_b ? "all on device!" : "does not fit");
+  if (need >= (double)free_b)
+    throw std::runtime_error("FFT: Unable to run on GPU due to memory constraints");
   return std::unique_ptr<Engine>(new Engine(dev, ext, V));
 }
 
 static void give_back_engine(int dev, std::unique_ptr<Engine> e) {
-  if (engine_cache_enabled()) engine_cache()[dev] = std::move(e);
+  if (!engine_cache_enabled()) return;
+  std::unique_ptr<Engine> old;  // destroyed outside the lock
+  {
+    std::lock_guard<std::mutex> lk(engine_cache_mutex());
+    auto& slot = engine_cache()[dev];
+    old = std::move(slot);
+    slot = std::move(e);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// padding policy of inplace_gpu_deconvolve
+//   MVN_PAD_ZERO (default)  the reference GPU entry's zero_padd (src/multiviewnative.cu:26-27,128;
+//                           inc/padd_utils.h:121-138; src/gpu_deconvolve_methods.cuh:366-449,
+//                           537-549): every stack is embedded at offset (kernel-1)/2 in a zero
+//                           volume of extent >= image + kernel - 1 (maxima over views and both
+//                           kernels), the loop runs cyclically on that volume, psi is cropped back
+//                           on exit.  The padded extents grow to FFT-friendly sizes (see
+//                           good_extent); the quotient is guarded (view == 0 -> 0) because the
+//                           extra zeros lie beyond the PSF's reach.
+//   MVN_PAD_ZERO_EXACT      the same with exactly image + kernel - 1 (the reference's extents; a
+//                           prime factor such as 542 = 2 * 271 then goes the chirp-z route)
+//   MVN_PAD_NONE            the reference CPU path's no_padd: cyclic on exactly image_dims_
+//                           (inc/cpu_convolve.h:22-26) -- the parity target of the oracle tests
+// Selected by mvn_set_pad_mode() (a JVM host cannot easily change its environment per call),
+// else by the environment variable MVN_PAD_MODE = zero | zero_exact | none (MVN_PAD_GOOD_SIZE=0
+// turns "zero" into "zero_exact"), else MVN_PAD_ZERO.
+// ---------------------------------------------------------------------------------------------
+enum { MVN_PAD_UNSET = -1, MVN_PAD_ZERO = 0, MVN_PAD_ZERO_EXACT = 1, MVN_PAD_NONE = 2 };
+static std::atomic<int> g_pad_mode{MVN_PAD_UNSET};
+
+static int parse_pad_mode(const char* m) {
+  if (!m || !*m) return MVN_PAD_UNSET;
+  if (std::strcmp(m, "zero") == 0) return MVN_PAD_ZERO;
+  if (std::strcmp(m, "zero_exact") == 0) return MVN_PAD_ZERO_EXACT;
+  if (std::strcmp(m, "none") == 0) return MVN_PAD_NONE;
+  throw std::invalid_argument(std::string("unknown padding mode '") + m + "' (zero | zero_exact | none)");
+}
+
+static int current_pad_mode() {
+  int m = g_pad_mode.load();
+  if (m == MVN_PAD_UNSET) m = parse_pad_mode(std::getenv("MVN_PAD_MODE"));
+  if (m == MVN_PAD_UNSET) m = MVN_PAD_ZERO;
+  if (m == MVN_PAD_ZERO) {
+    const char* gs = std::getenv("MVN_PAD_GOOD_SIZE");
+    if (gs && std::strcmp(gs, "0") == 0) m = MVN_PAD_ZERO_EXACT;
+  }
+  return m;
+}
+
+// Padded extent >= n for one axis.  Any 2^a 3^b 5^c 7^d length avoids the chirp-z route; the
+// lengths served by the fixed-length kernels (mvn_fixed_geom.hpp) run ~1.45x faster per element
+// than the run-time-radix ones, so a slightly longer fixed length can be the cheaper transform
+// (542 -> 576 rather than 560; 270 -> 320).  Candidates up to 1.3 n are priced by
+// length x (fixed ? 1 : 1.45).  The last axis (d2 = 2H) must be even to have fixed kernels.
+static int good_extent(int n, bool last_axis) {
+  int best = 0;
+  double best_cost = 0;
+  for (int c = n; c <= n + n * 3 / 10 + 8; ++c) {
+    int m = c;
+    for (int p : {2, 3, 5, 7})
+      while (m % p == 0) m /= p;
+    if (m != 1) continue;
+    int T = 0, threads = 0;
+    size_t lds = 0;
+    const bool fixed = last_axis ? (c % 2 == 0 && fixed_rows_geom(c / 2, &T, &threads, &lds))
+                                 : fixed_strided_geom(c, &T, &threads, &lds);
+    const double cost = (double)c * (fixed ? 1.0 : 1.45);
+    if (!best || cost < best_cost) {
+      best = c;
+      best_cost = cost;
+    }
+  }
+  return best ? best : next_smooth(n);
 }
 
 static int pick_device(int device) {
@@ -171,30 +271,26 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
     if (!psi || !input.data_) throw std::invalid_argument("null psi or workspace");
     const int V = input.num_views_;
     if (V == 0 || input.num_iterations_ <= 0) return;  // 0 iterations returns psi unchanged
-    const int dev = pick_device(device);
-    std::lock_guard<std::mutex> lk(device_mutex(dev));
-    const shape_t dims = to_shape(input.data_[0].image_dims_);
-    for (int v = 0; v < V; ++v) {
+    for (int v = 0; v < V; ++v) {  // before anything is dereferenced
       const view_data& d = input.data_[v];
       if (!d.image_ || !d.kernel1_ || !d.kernel2_ || !d.weights_ || !d.image_dims_ ||
           !d.kernel1_dims_ || !d.kernel2_dims_)
         throw std::invalid_argument("view " + std::to_string(v) + " has null members");
+    }
+    const shape_t dims = to_shape(input.data_[0].image_dims_);
+    for (int v = 0; v < V; ++v) {
+      const view_data& d = input.data_[v];
       if (to_shape(d.image_dims_) != dims)
         throw std::invalid_argument("all views must share image_dims_ (view " + std::to_string(v) + ")");
       if (d.weights_dims_ && to_shape(d.weights_dims_) != dims)
         throw std::invalid_argument("weights_dims_ must equal image_dims_ (view " + std::to_string(v) + ")");
     }
-    // Padding policy.  Default = the CPU path's no_padd (cyclic on exactly image_dims_, the parity
-    // target).  MVN_PAD_MODE=zero selects the reference GPU entry's zero_padd
-    // (src/multiviewnative.cu:26-27,128; inc/padd_utils.h:121-138;
-    // src/gpu_deconvolve_methods.cuh:366-449,537-549): every stack is embedded at offset
-    // (kernel-1)/2 in a zero volume of extent image + kernel - 1 (maxima over views and both
-    // kernels), the loop runs cyclically on that volume and psi is cropped back on exit.
-    const char* pm = std::getenv("MVN_PAD_MODE");
-    const bool zero_pad = pm && std::strcmp(pm, "zero") == 0;
+    for (int d = 0; d < 3; ++d)
+      if (dims[d] < 1) throw std::invalid_argument("image extents must be >= 1");
+    const int pad_mode = current_pad_mode();  // see the block comment above good_extent()
     shape_t ext = dims;
     int off[3] = {0, 0, 0};
-    if (zero_pad) {
+    if (pad_mode != MVN_PAD_NONE) {
       for (int d = 0; d < 3; ++d) {
         int kmax = 1;
         for (int v = 0; v < V; ++v) {
@@ -203,137 +299,90 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
         }
         ext[d] = dims[d] + kmax - 1;
         off[d] = (kmax - 1) / 2;
+        if (pad_mode == MVN_PAD_ZERO) ext[d] = good_extent(ext[d], d == 2);
       }
     }
-    // MVN_PAD_GOOD_SIZE=1 (zero mode only): grow every padded extent to the next 2^a 3^b 5^c 7^d
-    // so that no axis needs the O(r^2) prime stage (542 = 2*271 -> 560).  The extra zeros lie
-    // beyond the PSF's reach, where the blurred estimate is exactly or nearly 0; the quotient is
-    // therefore guarded (view == 0 -> 0) in this mode, the one deliberate deviation from the
-    // reference's pointwise math (which yields 0 * 1/0 = NaN there).
-    const char* gs = std::getenv("MVN_PAD_GOOD_SIZE");
-    const bool good_size = zero_pad && gs && *gs && std::strcmp(gs, "0") != 0;
-    if (good_size)
-      for (int d = 0; d < 3; ++d) {
-        int n = ext[d];
-        for (;; ++n) {
-          int m = n;
-          for (int p : {2, 3, 5, 7})
-            while (m % p == 0) m /= p;
-          if (m == 1) break;
-        }
-        ext[d] = n;
-      }
-    // memory heuristic of src/multiviewnative.cu:94-119, restated for the resident layout:
-    // 4 volumes per view (view, weights, two spectra) + psi + work (+ slack)
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lk(device_mutex(dev));
     be::set_device(dev);
-    Layout L(ext[0], ext[1], ext[2]);
-    const double need = (4.0 * V + 2.0) * (double)L.B() * 1.02;
-    size_t free_b = 0, total_b = 0;
-    be::device_mem_info(&free_b, &total_b);
-    if (trace_on())
-      std::printf("[lmvn::inplace_gpu_deconvolve] FFT: %.1f MB (all-on-device), available on GPU: %.1f MB ... %s\n",
-                  need / 1048576.0, free_b / 1048576.0, need < free_b ? "all on device!" : "does not fit");
-    if (need >= (double)free_b)
-      throw std::runtime_error("FFT: Unable to run on GPU due to memory constraints");
     std::unique_ptr<Engine> eng_owner = take_engine(dev, ext, V);  // on failure it is simply dropped
     Engine& eng = *eng_owner;
     eng.begin_call();
-    eng.set_quotient_guard(good_size);
-    if (!zero_pad) {
-      static const bool no_pipeline = [] {
-        const char* e = std::getenv("MVN_NO_PIPELINE");
-        return e && *e && std::strcmp(e, "0") != 0;
-      }();
-      if (no_pipeline) {
-        for (int v = 0; v < V; ++v) {
-          const view_data& d = input.data_[v];
-          eng.set_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
-        }
-        eng.set_psi(psi);
-        eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
-      } else {
-        // stacks arrive view by view from a second host thread while the first iteration already
-        // runs on the views that are in (the reference's interleaved driver)
-        auto t0 = std::chrono::steady_clock::now();
-        auto lap = [&](const char* what) {
-          if (!trace_on()) return;
-          auto t1 = std::chrono::steady_clock::now();
-          std::printf("[lmvn::trace] %-28s %8.1f ms\n", what,
-                      std::chrono::duration<double, std::milli>(t1 - t0).count());
-          t0 = t1;
-        };
-        eng.reserve_views();
-        lap("allocate view buffers");
-        eng.set_psi(psi);
-        lap("upload psi");
-        std::exception_ptr up_err;
-        std::thread uploader([&] {
-          try {
-            auto u0 = std::chrono::steady_clock::now();
-            for (int v = 0; v < V; ++v) {
-              const view_data& d = input.data_[v];
-              eng.stage_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
-            }
-            eng.finish_staging();
-            if (trace_on())
-              std::printf("[lmvn::trace] %-28s %8.1f ms (uploader thread)\n", "stage all views",
-                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count());
-          } catch (...) {
-            up_err = std::current_exception();
-            eng.staging_failed();
-          }
-        });
-        std::exception_ptr main_err;
-        try {
-          eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
-        } catch (...) {
-          main_err = std::current_exception();
-        }
-        lap("enqueue iterations");
-        uploader.join();
-        lap("join uploader");
-        if (up_err) std::rethrow_exception(up_err);
-        if (main_err) std::rethrow_exception(main_err);
-        eng.sync();
-        lap("wait for the device");
-        eng.get_psi(psi);
-        lap("download psi");
-        give_back_engine(dev, std::move(eng_owner));
-        return;
+    // stacks are embedded into / cropped out of the padded volume by the transfers themselves
+    // (strided device copies), so the padded modes keep the pipelined upload
+    const int dims_i[3] = {dims[0], dims[1], dims[2]};
+    eng.set_embedding(dims_i, off);
+    // extra zeros beyond the PSF's reach: the blurred estimate is exactly or nearly 0 there and
+    // the reference's pointwise math would give 0 * 1/0 = NaN; the one deliberate deviation
+    eng.set_quotient_guard(pad_mode == MVN_PAD_ZERO);
+    static const bool no_pipeline = [] {
+      const char* e = std::getenv("MVN_NO_PIPELINE");
+      return e && *e && std::strcmp(e, "0") != 0;
+    }();
+    if (no_pipeline) {
+      for (int v = 0; v < V; ++v) {
+        const view_data& d = input.data_[v];
+        eng.set_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
       }
+      eng.set_psi(psi);
+      eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
       eng.sync();
       eng.get_psi(psi);
       give_back_engine(dev, std::move(eng_owner));
       return;
     }
-    // zero_padd: embed on the host (insert_at_offsets, inc/padd_utils.h:160-190), crop on exit
-    const size_t en = (size_t)ext[0] * ext[1] * ext[2];
-    auto embed = [&](const float* src, std::vector<float>& dst) {
-      std::fill(dst.begin(), dst.end(), 0.f);
-      for (int z = 0; z < dims[0]; ++z)
-        for (int y = 0; y < dims[1]; ++y)
-          std::memcpy(&dst[((size_t)(z + off[0]) * ext[1] + (y + off[1])) * ext[2] + off[2]],
-                      src + ((size_t)z * dims[1] + y) * dims[2], sizeof(float) * (size_t)dims[2]);
+    // stacks arrive view by view from a second host thread while the first iteration already
+    // runs on the views that are in (the reference's interleaved driver)
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!trace_on()) return;
+      auto t1 = std::chrono::steady_clock::now();
+      std::printf("[lmvn::trace] %-28s %8.1f ms\n", what,
+                  std::chrono::duration<double, std::milli>(t1 - t0).count());
+      t0 = t1;
     };
-    std::vector<float> a(en), b(en);
-    for (int v = 0; v < V; ++v) {
-      const view_data& d = input.data_[v];
-      embed(d.image_, a);
-      embed(d.weights_, b);
-      eng.set_view(v, a.data(), b.data(), d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+    eng.reserve_views();
+    lap("allocate view buffers");
+    eng.set_psi(psi);
+    lap("upload psi");
+    std::exception_ptr up_err;
+    std::thread uploader([&] {
+      try {
+        auto u0 = std::chrono::steady_clock::now();
+        for (int v = 0; v < V; ++v) {
+          const view_data& d = input.data_[v];
+          eng.stage_view(v, d.image_, d.weights_, d.kernel1_, d.kernel1_dims_, d.kernel2_, d.kernel2_dims_);
+        }
+        eng.finish_staging();
+        if (trace_on())
+          std::printf("[lmvn::trace] %-28s %8.1f ms (uploader thread)\n", "stage all views",
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count());
+      } catch (...) {
+        up_err = std::current_exception();
+        eng.staging_failed();
+      }
+    });
+    std::exception_ptr main_err;
+    try {
+      eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
+    } catch (...) {
+      main_err = std::current_exception();
     }
-    embed(psi, a);
-    eng.set_psi(a.data());
-    eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
+    lap("enqueue iterations");
+    uploader.join();
+    lap("join uploader");
+    if (up_err) std::rethrow_exception(up_err);
+    if (main_err) std::rethrow_exception(main_err);
     eng.sync();
-    eng.get_psi(a.data());
-    for (int z = 0; z < dims[0]; ++z)
-      for (int y = 0; y < dims[1]; ++y)
-        std::memcpy(psi + ((size_t)z * dims[1] + y) * dims[2],
-                    &a[((size_t)(z + off[0]) * ext[1] + (y + off[1])) * ext[2] + off[2]],
-                    sizeof(float) * (size_t)dims[2]);
+    lap("wait for the device");
+    eng.get_psi(psi);
+    lap("download psi");
     give_back_engine(dev, std::move(eng_owner));
   });
+}
+
+int mvn_set_pad_mode(const char* mode) {
+  return guarded("mvn_set_pad_mode", [&] { g_pad_mode.store(parse_pad_mode(mode)); });
 }
 
 // single convolution on the engine's kernels; shared by the three convolution entry points
@@ -603,10 +652,13 @@ void compute_final_values(imageType* _image, imageType* _integral, imageType* _w
 int mvn_release_cached_engines(void) {
   return guarded("mvn_release_cached_engines", [&] {
     std::vector<int> devs;
-    for (auto& kv : engine_cache()) devs.push_back(kv.first);
+    {
+      std::lock_guard<std::mutex> lk(engine_cache_mutex());
+      for (auto& kv : engine_cache()) devs.push_back(kv.first);
+    }
     for (int d : devs) {
-      std::lock_guard<std::mutex> lk(device_mutex(d));
-      engine_cache().erase(d);
+      std::lock_guard<std::mutex> lk(device_mutex(d));  // not while a call on that device runs
+      pop_cached_engine(d).reset();
     }
   });
 }

@@ -83,6 +83,13 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
 void launch_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
                         int D1, int D2, long pitch, float scale, stream_t s);
 
+// strided 3-D copy of floats, dst[z][y][x] = src[z][y][x] for x < nx, y < ny, z < nz with row /
+// plane pitches in floats: embeds a dense stack into a zero-padded volume and crops it back
+// (insert_at_offsets / the crop on exit, inc/padd_utils.h:160-190, src/gpu_deconvolve_methods.cuh:
+// 537-549, done by the reference on the host)
+void launch_copy3d(float* dst, long drow, long dplane, const float* src, long srow, long splane,
+                   int nx, int ny, int nz, stream_t s);
+
 // stand-alone pointwise ops on flat arrays (legacy ABI: compute_quotient / compute_final_values)
 void launch_divide(const float* view, float* inout, size_t n, stream_t s);
 void launch_update(float* psi, const float* integral, const float* weights, size_t n,

@@ -13,7 +13,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -36,17 +38,35 @@ namespace be {
 
 const char* backend_name() { return "host-emulation (test only)"; }
 
-int device_count() { return 1; }
-void set_device(int) {}
-int get_device() { return 0; }
+// MVN_EMU_DEVICES=n pretends to have n devices (tests of the per-device engine cache and locking);
+// the current device is per host thread, as in HIP
+int device_count() {
+  const char* e = std::getenv("MVN_EMU_DEVICES");
+  const int n = e ? std::atoi(e) : 1;
+  return n > 0 ? n : 1;
+}
+static thread_local int t_device = 0;
+void set_device(int d) { t_device = d; }
+int get_device() { return t_device; }
 void device_name(int, char* name256) {
   std::memset(name256, 0, 256);
   std::strcpy(name256, "mvn host emulation");
 }
-long long device_total_mem(int) { return 8LL << 30; }
+// "device memory" accounting per fake device: total = MVN_EMU_TOTAL_MB (default 8 GiB), free =
+// total - live dmalloc bytes, so that the memory heuristic of the ABI call can be tested
+static std::mutex g_mem_mu;
+static std::map<void*, std::pair<int, size_t>> g_live;  // pointer -> (device, bytes)
+static std::map<int, size_t> g_used;
+static size_t emu_total() {
+  const char* e = std::getenv("MVN_EMU_TOTAL_MB");
+  return e ? (size_t)std::atoll(e) << 20 : (size_t)8 << 30;
+}
+long long device_total_mem(int) { return (long long)emu_total(); }
 void device_mem_info(size_t* f, size_t* t) {
-  *f = (size_t)8 << 30;
-  *t = (size_t)8 << 30;
+  std::lock_guard<std::mutex> lk(g_mem_mu);
+  const size_t total = emu_total(), used = g_used[t_device];
+  *t = total;
+  *f = used < total ? total - used : 0;
 }
 void device_arch(int, int* major, int* minor) {
   *major = 0;
@@ -56,9 +76,23 @@ void device_arch(int, int* major, int* minor) {
 void* dmalloc(size_t bytes) {
   void* p = std::malloc(bytes ? bytes : 1);
   if (!p) throw std::bad_alloc();
+  std::lock_guard<std::mutex> lk(g_mem_mu);
+  g_live[p] = std::make_pair(t_device, bytes);
+  g_used[t_device] += bytes;
   return p;
 }
-void dfree(void* p) { std::free(p); }
+void dfree(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    auto it = g_live.find(p);
+    if (it != g_live.end()) {
+      g_used[it->second.first] -= it->second.second;
+      g_live.erase(it);
+    }
+  }
+  std::free(p);
+}
 void h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
 void d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }
 void d2d(void* dst, const void* src, size_t bytes, stream_t) { std::memmove(dst, src, bytes); }
@@ -314,6 +348,13 @@ void launch_scatter_psf(const float* kernel, int k0, int k1, int k2, float* targ
                         int D1, int D2, long pitch, float scale, stream_t) {
   const long total = (long)k0 * k1 * k2;
   for (long i = 0; i < total; ++i) mvn_scatter_psf_item(kernel, k0, k1, k2, target, D0, D1, D2, pitch, scale, i);
+}
+
+void launch_copy3d(float* dst, long drow, long dplane, const float* src, long srow, long splane,
+                   int nx, int ny, int nz, stream_t) {
+  for (long z = 0; z < nz; ++z)
+    for (long y = 0; y < ny; ++y)
+      std::memcpy(dst + z * dplane + y * drow, src + z * splane + y * srow, sizeof(float) * (size_t)nx);
 }
 
 void launch_divide(const float* view, float* inout, size_t n, stream_t) {

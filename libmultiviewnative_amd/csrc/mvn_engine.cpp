@@ -567,6 +567,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   be::dzero(work_, mb, stream_);
   if (plan_->nyq_bytes()) work_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
   views_.resize((size_t)num_views);
+  for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);
 }
 
@@ -589,6 +590,7 @@ Engine::~Engine() {
   be::dfree(work_nyq_);
   be::dfree(psi_spec_);
   be::dfree(psi_spec_nyq_);
+  be::dfree(embed_scratch_);
   be::graph_destroy(sweep_graph_);
   if (!delta_external_) be::dfree(delta_);
   try {
@@ -606,8 +608,44 @@ Engine::~Engine() {
   if (stream_) be::stream_destroy(stream_);
 }
 
+void Engine::set_embedding(const int dims[3], const int off[3]) {
+  be::set_device(device_);
+  const Layout& L = plan_->L;
+  const int ext[3] = {L.d0, L.d1, L.d2};
+  bool dense = true, same = true;
+  for (int d = 0; d < 3; ++d) {
+    if (dims[d] < 1 || off[d] < 0 || off[d] + dims[d] > ext[d])
+      throw std::invalid_argument("mvn: embedded stack does not fit the engine volume");
+    dense = dense && dims[d] == ext[d];
+    same = same && host_dims_[d] == dims[d] && host_off_[d] == off[d];
+  }
+  if (same && embedded_ == !dense) return;
+  be::stream_sync(stream_);
+  // the interior moves: what used to be interior may now be padding and must read zero
+  for (size_t v = 0; v < views_.size(); ++v) {
+    if (views_[v].image) be::dzero(views_[v].image, plan_->main_bytes(), stream_);
+    if (views_[v].weights) be::dzero(views_[v].weights, plan_->main_bytes(), stream_);
+  }
+  be::stream_sync(stream_);
+  be::dfree(embed_scratch_);
+  embed_scratch_ = nullptr;
+  for (int d = 0; d < 3; ++d) {
+    host_dims_[d] = dims[d];
+    host_off_[d] = off[d];
+  }
+  embedded_ = !dense;
+  if (embedded_) embed_scratch_ = (float*)be::dmalloc(host_floats() * sizeof(float));
+}
+
 void Engine::upload_volume(float* dst, const float* host, be::stream_t s) {
   const Layout& L = plan_->L;
+  if (embedded_) {
+    be::h2d(embed_scratch_, host, host_floats() * sizeof(float), s);
+    be::launch_copy3d(dst + ((size_t)host_off_[0] * L.d1 + host_off_[1]) * L.RP + host_off_[2], L.RP,
+                      (long)L.d1 * L.RP, embed_scratch_, host_dims_[2], (long)host_dims_[1] * host_dims_[2],
+                      host_dims_[2], host_dims_[1], host_dims_[0], s);
+    return;
+  }
   if (L.RP == L.d2)
     be::h2d(dst, host, L.logical() * sizeof(float), s);
   else
@@ -626,7 +664,7 @@ void Engine::alloc_view(ViewSlot& s) {
     s.nyq1 = (cfloat*)be::dmalloc(nb);
     s.nyq2 = (cfloat*)be::dmalloc(nb);
   }
-  if (plan_->L.RP != plan_->L.d2) {  // odd d2: the row pad must hold zeros
+  if (plan_->L.RP != plan_->L.d2 || embedded_) {  // odd d2 / embedded stacks: the padding must hold zeros
     be::dzero(s.image, mb, stream_);
     be::dzero(s.weights, mb, stream_);
     be::stream_sync(stream_);
@@ -761,6 +799,7 @@ void Engine::wait_staged(int v) {
 void Engine::set_psi(const float* host) {
   be::set_device(device_);
   psi_spec_valid_ = false;
+  if (embedded_) be::dzero(psi_, plan_->main_bytes(), stream_);
   upload_volume(psi_, host, stream_);
   be::stream_sync(stream_);
 }
@@ -768,6 +807,14 @@ void Engine::set_psi(const float* host) {
 void Engine::get_psi(float* host) {
   be::set_device(device_);
   const Layout& L = plan_->L;
+  if (embedded_) {
+    be::launch_copy3d(embed_scratch_, host_dims_[2], (long)host_dims_[1] * host_dims_[2],
+                      psi_ + ((size_t)host_off_[0] * L.d1 + host_off_[1]) * L.RP + host_off_[2], L.RP,
+                      (long)L.d1 * L.RP, host_dims_[2], host_dims_[1], host_dims_[0], stream_);
+    be::d2h(host, embed_scratch_, host_floats() * sizeof(float), stream_);
+    be::stream_sync(stream_);
+    return;
+  }
   if (L.RP == L.d2)
     be::d2h(host, psi_, L.logical() * sizeof(float), stream_);
   else

@@ -259,6 +259,11 @@ class Engine {
   void bind_delta(float* external);
   float* psi_ptr() { return psi_; }
   size_t volume_floats() const { return plan_->L.real_floats(); }
+  // Host stacks of extents `dims` live at offset `off` inside the engine's (larger) volume, the
+  // rest of which holds zeros: set_view / stage_view / set_psi embed, get_psi crops (the
+  // reference's zero_padd policy, inc/padd_utils.h:121-190, without the host-side staging
+  // copies).  dims == engine extents and off == 0 is the dense default.
+  void set_embedding(const int dims[3], const int off[3]);
   // quotient 0 wherever the view is exactly 0 (see EpilogueParams::guard_zero_view)
   void set_quotient_guard(bool on) { quotient_guard_ = on; }
   // a cached engine starts every ABI call from a clean per-call state
@@ -279,6 +284,10 @@ class Engine {
   void conv_pair(int v, double lambda, float min_value, int final_mode, int accumulate,
                  bool feed_next);
   void upload_volume(float* dst, const float* host, be::stream_t s);
+  bool embedded_ = false;
+  int host_dims_[3] = {0, 0, 0}, host_off_[3] = {0, 0, 0};
+  float* embed_scratch_ = nullptr;  // one dense host-shaped stack: H2D lands here, a strided device copy embeds it
+  size_t host_floats() const { return (size_t)host_dims_[0] * host_dims_[1] * host_dims_[2]; }
   void alloc_view(ViewSlot& s);
   void wait_staged(int v);
   int device_;

@@ -127,6 +127,19 @@ __global__ void k_scatter_psf(const float* kernel, int k0, int k1, int k2, float
     mvn_scatter_psf_item(kernel, k0, k1, k2, target, D0, D1, D2, pitch, scale, i);
 }
 
+// one workgroup row per (y, z): x runs over lanes, so both sides are read / written in contiguous
+// runs whatever the offsets are
+__global__ void k_copy3d(float* __restrict__ dst, long drow, long dplane, const float* __restrict__ src,
+                         long srow, long splane, int nx, int ny, int nz) {
+  const long rows = (long)ny * nz;
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long z = r / ny, y = r - z * ny;
+    const float* s = src + z * splane + y * srow;
+    float* d = dst + z * dplane + y * drow;
+    for (int x = threadIdx.x; x < nx; x += blockDim.x) d[x] = s[x];
+  }
+}
+
 __global__ void k_divide(const float* __restrict__ view, float* __restrict__ inout, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -346,24 +359,34 @@ static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t
 // MVN_PERSIST=k (k > 1) launches k times the resident number.  The LDS-staged fused pass is
 // launched one workgroup per tile: measured at 512^3, 0.333 ms against 0.380 ms walking (the
 // walking workgroups of a CU stay in step, all loading or all computing at once).
+static int current_device() {
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  return dev;
+}
+
+// CUs of the current device (asked once per device)
 static int device_cu_count() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-  }
+  static std::mutex mu;
+  static std::map<int, int> cache;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(dev);
+  if (it != cache.end()) return it->second;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+  cache[dev] = cus;
   return cus;
 }
 
-// resident workgroups per CU of a (kernel, block size, LDS) triple: asked once, not per launch
+// resident workgroups per CU of a (device, kernel, block size, LDS) tuple: asked once, not per launch
 static int resident_per_cu(const void* kernel, int nthreads, size_t lds_bytes) {
   static std::mutex mu;
-  static std::map<std::tuple<const void*, int, size_t>, int> cache;
+  static std::map<std::tuple<int, const void*, int, size_t>, int> cache;
+  const int dev = current_device();
   std::lock_guard<std::mutex> lk(mu);
-  const auto key = std::make_tuple(kernel, nthreads, lds_bytes);
+  const auto key = std::make_tuple(dev, kernel, nthreads, lds_bytes);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   int per_cu = 0;
@@ -566,6 +589,17 @@ void launch_scatter_psf(const float* kernel, int k0, int k1, int k2, float* targ
   const size_t total = (size_t)k0 * k1 * k2;
   hipLaunchKernelGGL(k_scatter_psf, dim3(flat_grid(total, 256)), dim3(256), 0, hs(s), kernel, k0,
                      k1, k2, target, D0, D1, D2, pitch, scale);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_copy3d(float* dst, long drow, long dplane, const float* src, long srow, long splane,
+                   int nx, int ny, int nz, stream_t s) {
+  if (nx < 1 || ny < 1 || nz < 1) return;
+  const long rows = (long)ny * nz;
+  const int block = nx >= 256 ? 256 : (nx >= 128 ? 128 : 64);
+  const unsigned grid = (unsigned)(rows < 256L * 32 ? rows : 256L * 32);
+  hipLaunchKernelGGL(k_copy3d, dim3(grid), dim3(block), 0, hs(s), dst, drow, dplane, src, srow, splane,
+                     nx, ny, nz);
   HIP_CHECK(hipGetLastError());
 }
 

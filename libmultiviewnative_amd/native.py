@@ -28,7 +28,7 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
@@ -68,6 +68,7 @@ class Binding:
         l.mvn_split_launch_count.argtypes = []
         l.mvn_kernel_kind_name.restype = C.c_char_p
         l.mvn_kernel_kind_name.argtypes = [C.c_int]
+        l.mvn_set_pad_mode.argtypes = [C.c_char_p]
         l.inplace_gpu_deconvolve.argtypes = [c_float_p, Workspace, C.c_int]
         l.inplace_gpu_deconvolve.restype = None
         for n in ("inplace_gpu_convolution", "convolution3DfftCUDAInPlace"):
@@ -151,10 +152,23 @@ class Binding:
     def backend_name(self):
         return self.l.mvn_backend_name().decode()
 
+    def set_pad_mode(self, mode):
+        """'zero' | 'zero_exact' | 'none' | None (back to MVN_PAD_MODE / the default)."""
+        self.check(self.l.mvn_set_pad_mode(mode.encode() if mode else None))
+
     # ---- reference ABI, numpy in / numpy out ----------------------------------------------
-    def gpu_deconvolve(self, psi, holder, device=0):
+    def gpu_deconvolve(self, psi, holder, device=0, pad_mode="none"):
+        """inplace_gpu_deconvolve on a copy of psi.  `pad_mode` defaults to the CPU path's cyclic
+        policy, the one the oracle implements (the library's own default is 'zero', the reference
+        GPU entry's); pass pad_mode=False to leave the process-wide setting alone."""
         out = np.ascontiguousarray(psi, dtype=np.float32).copy()
-        self.l.inplace_gpu_deconvolve(fptr(out), holder.ws, device)
+        if pad_mode is not False:
+            self.set_pad_mode(pad_mode)
+        try:
+            self.l.inplace_gpu_deconvolve(fptr(out), holder.ws, device)
+        finally:
+            if pad_mode is not False:
+                self.set_pad_mode(None)
         return out
 
     def gpu_convolution(self, image, kernel, device=0, legacy=False):

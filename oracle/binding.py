@@ -54,6 +54,8 @@ def _setup(l):
     l.oracle_set_quotient_guard.restype = None
     l.oracle_last_timing.argtypes = [C.POINTER(C.c_double)]
     l.oracle_last_timing.restype = None
+    l.oracle_fft_backend.argtypes = []
+    l.oracle_fft_backend.restype = C.c_char_p
     l.oracle_threads.argtypes = [C.c_int]
     l.oracle_threads.restype = C.c_int
     l.oracle_spatial_convolve.argtypes = [c_float_p, c_int_p, c_float_p, c_int_p, c_float_p]
@@ -177,6 +179,12 @@ def last_timing():
     t = (C.c_double * 2)()
     lib().oracle_last_timing(t)
     return t[0], t[1]
+
+
+def fft_backend():
+    """'fftw' when libfftw3f.so.3 could be dlopen'ed on this host (the reference's FFT library),
+    else 'port' (the oracle's own transform)."""
+    return lib().oracle_fft_backend().decode()
 
 
 def threads(nthreads):

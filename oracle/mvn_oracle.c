@@ -246,7 +246,7 @@ static void axis_pass(cpx* data, long outer, int n, long inner, int sign, int nt
  * [d0][d1][2*(d2/2+1)] floats (inc/fft_utils.h:55-85 -> fftwf_execute_dft_r2c with the plan
  * of inc/plan_store.h:116-118; layout inc/image_stack_utils.h:24-42).
  */
-static void rfft3_forward_nt(float* buf, int d0, int d1, int d2, int nthreads) {
+static void builtin_forward_nt(float* buf, int d0, int d1, int d2, int nthreads) {
   const int nc = d2 / 2 + 1;
   const long rows = (long)d0 * d1;
   const plan1d* pl = get_plan(d2);
@@ -271,7 +271,7 @@ static void rfft3_forward_nt(float* buf, int d0, int d1, int d2, int nthreads) {
 }
 
 /* inverse of the above, un-normalised (inc/fft_utils.h:87-104 -> fftwf_execute_dft_c2r) */
-static void rfft3_backward_nt(float* buf, int d0, int d1, int d2, int nthreads) {
+static void builtin_backward_nt(float* buf, int d0, int d1, int d2, int nthreads) {
   const int nc = d2 / 2 + 1;
   const long rows = (long)d0 * d1;
   const plan1d* pl = get_plan(d2);
@@ -296,6 +296,128 @@ static void rfft3_backward_nt(float* buf, int d0, int d1, int d2, int nthreads) 
     free(a);
     free(b);
   }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Optional FFTW backend.  The reference's CPU path calls FFTW3 single precision
+ * (fftwf_plan_dft_r2c_3d / c2r_3d with FFTW_MEASURE, inc/plan_store.h:116-122;
+ * fftwf_execute_dft_r2c / c2r, inc/fft_utils.h:84,103; threads via fftwf_init_threads +
+ * fftwf_plan_with_nthreads, inc/fft_utils.h:180-197).  FFTW is not in this image, so nothing is
+ * linked: when libfftw3f.so.3 can be dlopen'ed at run time (MVN_ORACLE_FFTW_LIB overrides the
+ * name, MVN_ORACLE_FFTW=0 disables the probe) the 3-D transforms go through it -- bench.py's CPU
+ * baseline is then literally the reference's FFT library ("kind": "fftw") -- otherwise through
+ * the built-in transform above ("port").  Plans are cached per (shape, threads), like plan_store.
+ * ---------------------------------------------------------------------------------------- */
+#include <dlfcn.h>
+
+typedef void* fftwf_plan_t;
+typedef struct fftw_api {
+  int state; /* 0 not probed, 1 loaded, -1 unavailable */
+  int threads_ok;
+  fftwf_plan_t (*plan_r2c)(int, int, int, float*, float*, unsigned);
+  fftwf_plan_t (*plan_c2r)(int, int, int, float*, float*, unsigned);
+  void (*exec_r2c)(fftwf_plan_t, float*, float*);
+  void (*exec_c2r)(fftwf_plan_t, float*, float*);
+  void (*destroy)(fftwf_plan_t);
+  int (*init_threads)(void);
+  void (*plan_with_nthreads)(int);
+} fftw_api;
+static fftw_api g_fftw;
+
+typedef struct fftw_plans {
+  int d0, d1, d2, nthreads;
+  fftwf_plan_t fwd, bwd;
+  struct fftw_plans* next;
+} fftw_plans;
+static fftw_plans* g_fftw_plans = NULL;
+
+static int fftw_ready(void) {
+  int st;
+#pragma omp critical(mvn_oracle_fftw)
+  {
+    if (g_fftw.state == 0) {
+      g_fftw.state = -1;
+      const char* off = getenv("MVN_ORACLE_FFTW");
+      if (!(off && strcmp(off, "0") == 0)) {
+        const char* name = getenv("MVN_ORACLE_FFTW_LIB");
+        void* h = dlopen(name && *name ? name : "libfftw3f.so.3", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+          *(void**)&g_fftw.plan_r2c = dlsym(h, "fftwf_plan_dft_r2c_3d");
+          *(void**)&g_fftw.plan_c2r = dlsym(h, "fftwf_plan_dft_c2r_3d");
+          *(void**)&g_fftw.exec_r2c = dlsym(h, "fftwf_execute_dft_r2c");
+          *(void**)&g_fftw.exec_c2r = dlsym(h, "fftwf_execute_dft_c2r");
+          *(void**)&g_fftw.destroy = dlsym(h, "fftwf_destroy_plan");
+          if (g_fftw.plan_r2c && g_fftw.plan_c2r && g_fftw.exec_r2c && g_fftw.exec_c2r) {
+            g_fftw.state = 1;
+            /* the threads API lives in the same library or in libfftw3f_omp / _threads
+             * (cmake/FindFFTW.cmake:47-115) */
+            const char* tl[3] = {NULL, "libfftw3f_omp.so.3", "libfftw3f_threads.so.3"};
+            for (int i = 0; i < 3 && !g_fftw.threads_ok; ++i) {
+              void* th = i == 0 ? h : dlopen(tl[i], RTLD_NOW | RTLD_GLOBAL);
+              if (!th) continue;
+              *(void**)&g_fftw.init_threads = dlsym(th, "fftwf_init_threads");
+              *(void**)&g_fftw.plan_with_nthreads = dlsym(th, "fftwf_plan_with_nthreads");
+              if (g_fftw.init_threads && g_fftw.plan_with_nthreads && g_fftw.init_threads())
+                g_fftw.threads_ok = 1;
+            }
+          }
+        }
+      }
+    }
+    st = g_fftw.state;
+  }
+  return st == 1;
+}
+
+/* "fftw" or "port": which transform the 3-D FFTs of this process go through */
+const char* oracle_fft_backend(void) { return fftw_ready() ? "fftw" : "port"; }
+
+static fftw_plans* fftw_get_plans(int d0, int d1, int d2, int nthreads) {
+  fftw_plans* p = NULL;
+#pragma omp critical(mvn_oracle_fftw)
+  {
+    for (p = g_fftw_plans; p; p = p->next)
+      if (p->d0 == d0 && p->d1 == d1 && p->d2 == d2 && p->nthreads == nthreads) break;
+    if (!p) {
+      /* FFTW_MEASURE (= 0, inc/plan_store.h:117,122) overwrites the arrays while planning:
+       * plan on a scratch volume, execute with the new-array interface */
+      const size_t nfl = (size_t)d0 * d1 * 2u * (size_t)(d2 / 2 + 1);
+      float* scratch = (float*)calloc(nfl, sizeof(float));
+      if (g_fftw.threads_ok) g_fftw.plan_with_nthreads(nthreads);
+      p = (fftw_plans*)calloc(1, sizeof(fftw_plans));
+      p->d0 = d0; p->d1 = d1; p->d2 = d2; p->nthreads = nthreads;
+      p->fwd = g_fftw.plan_r2c(d0, d1, d2, scratch, scratch, 0u);
+      p->bwd = g_fftw.plan_c2r(d0, d1, d2, scratch, scratch, 0u);
+      free(scratch);
+      p->next = g_fftw_plans;
+      g_fftw_plans = p;
+    }
+  }
+  return p;
+}
+
+static void rfft3_forward_nt(float* buf, int d0, int d1, int d2, int nthreads) {
+  if (fftw_ready()) {
+    fftw_plans* p = fftw_get_plans(d0, d1, d2, nthreads);
+    if (p->fwd) { g_fftw.exec_r2c(p->fwd, buf, buf); return; }
+  }
+  builtin_forward_nt(buf, d0, d1, d2, nthreads);
+}
+
+static void rfft3_backward_nt(float* buf, int d0, int d1, int d2, int nthreads) {
+  if (fftw_ready()) {
+    fftw_plans* p = fftw_get_plans(d0, d1, d2, nthreads);
+    if (p->bwd) { g_fftw.exec_c2r(p->bwd, buf, buf); return; }
+  }
+  builtin_backward_nt(buf, d0, d1, d2, nthreads);
+}
+
+/* the built-in transform whatever the backend (lets a test double of libfftw3f call back in) */
+void oracle_builtin_rfft3_forward(float* buf, int d0, int d1, int d2, int nthreads) {
+  builtin_forward_nt(buf, d0, d1, d2, resolve_threads(nthreads));
+}
+void oracle_builtin_rfft3_backward(float* buf, int d0, int d1, int d2, int nthreads) {
+  builtin_backward_nt(buf, d0, d1, d2, resolve_threads(nthreads));
 }
 
 void oracle_rfft3_forward(float* buf, int d0, int d1, int d2, int nthreads) {

@@ -300,17 +300,22 @@ def test_zero_padd_mode_matches_reference_gpu_policy(emu, monkeypatch):
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 3, 7))
     k2[1] = k2[1][:3]  # kernels of different extents: the policy takes the maxima
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
-    cyclic = emu.gpu_deconvolve(psi0, h)
-    monkeypatch.setenv("MVN_PAD_MODE", "zero")
-    padded = emu.gpu_deconvolve(psi0, h)
-    monkeypatch.delenv("MVN_PAD_MODE")
+    cyclic = emu.gpu_deconvolve(psi0, h)  # pad_mode="none", the CPU path's policy
+    padded = emu.gpu_deconvolve(psi0, h, pad_mode="zero_exact")  # exactly image + kernel - 1
     ref = _zero_padd_reference(orc, psi0, views, k1, k2, w, 0.006, 1e-4, 3)
     assert np.abs(padded - ref).max() <= 1e-4 * np.abs(ref).max()
     assert np.abs(padded - cyclic).max() > 1e-3 * np.abs(ref).max()  # the two policies do differ
+    # the same selection through the environment (what round 1 offered), the setter left alone
+    monkeypatch.setenv("MVN_PAD_MODE", "zero_exact")
+    assert np.array_equal(emu.gpu_deconvolve(psi0, h, pad_mode=False), padded)
+    monkeypatch.setenv("MVN_PAD_MODE", "none")
+    assert np.array_equal(emu.gpu_deconvolve(psi0, h, pad_mode=False), cyclic)
+    monkeypatch.delenv("MVN_PAD_MODE")
 
 
 def test_zero_padd_good_size_mode(emu, monkeypatch):
-    # MVN_PAD_GOOD_SIZE=1: padded extents grow to 2^a 3^b 5^c 7^d (here 19+5-1=23 -> 24,
+    # The library's DEFAULT policy (the reference GPU entry's zero_padd, src/multiviewnative.cu:
+    # 26-27,128) with FFT-friendly padded extents: they grow to 2^a 3^b 5^c 7^d (here 19+5-1=23 -> 24,
     # 13+3-1=15, 17+7-1=23 -> 24) and the quotient is guarded where the view is exactly 0.
     # Delta PSFs make the blurred estimate EXACTLY 0 in the border: without the guard -> NaN.
     shape = (19, 13, 17)
@@ -321,11 +326,10 @@ def test_zero_padd_good_size_mode(emu, monkeypatch):
     k2 = [np.ascontiguousarray(k) for k in k2]
     psi0 = np.full(shape, 3.0, np.float32)
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
-    monkeypatch.setenv("MVN_PAD_MODE", "zero")
-    monkeypatch.setenv("MVN_PAD_GOOD_SIZE", "1")
-    got = emu.gpu_deconvolve(psi0, h)
-    monkeypatch.delenv("MVN_PAD_MODE")
-    monkeypatch.delenv("MVN_PAD_GOOD_SIZE")
+    monkeypatch.delenv("MVN_PAD_MODE", raising=False)
+    monkeypatch.delenv("MVN_PAD_GOOD_SIZE", raising=False)
+    got = emu.gpu_deconvolve(psi0, h, pad_mode=False)  # no setter, no environment: the default
+    assert np.array_equal(got, emu.gpu_deconvolve(psi0, h, pad_mode="zero"))
     assert np.isfinite(got).all()
     # oracle on hand-padded stacks of the same good size, same guard
     ext, off = (24, 15, 24), (2, 1, 3)
@@ -515,3 +519,83 @@ def test_slab_engine_rejects_bad_decompositions(emu, capfd):
         e.bind_buffers(e.buffers()[0], None, None, None)  # partial binding
     e.close()
     capfd.readouterr()
+
+
+# ---- the ABI call's engine cache: several devices, memory heuristic -------------
+_CACHE_CHILD = r"""
+import os, sys, threading
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from libmultiviewnative_amd import native
+from libmultiviewnative_amd.abi import WorkspaceHolder
+from oracle import binding as orc
+from ref_fixtures import realistic_views
+emu = native.Binding(native.EMU_SO)
+mode = sys.argv[2]
+
+def case(shape, V, seed):
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (3, 3, 3), seed=seed)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    return h, psi0, orc.cpu_deconvolve(psi0, h, 1)
+
+if mode == "two_devices":
+    # Fiji's one-host-thread-per-device mode: both threads go through the process-wide engine cache
+    # (erase + insert on every call, shapes alternate so that engines are also replaced)
+    assert emu.l.getNumDevicesCUDA() == 2
+    cases = [[case((12, 10, 14), 2, 1), case((8, 12, 10), 1, 2)], [case((10, 8, 12), 2, 3), case((12, 10, 14), 1, 4)]]
+    emu.set_pad_mode("none")
+    bad = []
+    def work(dev):
+        for rep in range(12):
+            h, psi0, ref = cases[dev][rep % 2]
+            got = emu.gpu_deconvolve(psi0, h, device=dev, pad_mode=False)
+            if not np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max():
+                bad.append((dev, rep))
+    ts = [threading.Thread(target=work, args=(d,)) for d in (0, 1)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    emu.check(emu.l.mvn_release_cached_engines())
+    assert not bad, bad
+    print("ok")
+elif mode == "memory":
+    # total 16 MB; 64^3 x 2 views needs (4*2+2) * 1.08 MB * 1.02 = 11 MB > total / 2
+    big = case((64, 64, 64), 2, 5)
+    other = case((64, 64, 32), 2, 6)      # 5.6 MB: fits only once the stale engine has been freed
+    huge = case((64, 64, 128), 2, 7)      # 21.7 MB: never fits
+    emu.set_pad_mode("none")
+    for h, psi0, ref in (big, big, other, big):
+        got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), "a call that fits was rejected or wrong"
+    h, psi0, ref = huge
+    got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert np.array_equal(got, psi0), "psi must be left untouched when the stacks do not fit"
+    assert "memory constraints" in emu.l.mvn_last_error().decode()
+    h, psi0, ref = big                    # and the library keeps working afterwards
+    got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    print("ok")
+"""
+
+
+def _run_cache_child(mode, env_extra, tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2", **env_extra)
+    r = subprocess.run([sys.executable, "-c", _CACHE_CHILD, root, mode], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
+    return r
+
+
+def test_engine_cache_two_host_threads_two_devices(tmp_path):
+    # the cache map is process-wide, calls are serialised per device only: two host threads on two
+    # (emulated) devices must not corrupt it (mvn_abi.cpp: engine_cache_mutex)
+    _run_cache_child("two_devices", {"MVN_EMU_DEVICES": "2"}, tmp_path)
+
+
+def test_memory_heuristic_counts_the_cached_engine(tmp_path):
+    # src/multiviewnative.cu:94-140 restated: the check must not reject a block of the shape whose
+    # engine is already resident, nor count a stale engine that is about to be freed
+    r = _run_cache_child("memory", {"MVN_EMU_TOTAL_MB": "16"}, tmp_path)
+    assert "memory constraints" in r.stderr

@@ -522,17 +522,22 @@ def test_zero_padd_mode_matches_reference_gpu_policy(gpu, orc, monkeypatch):
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 3, 7))
     k2[1] = k2[1][:3]  # kernels of different extents: the policy takes the maxima
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
-    cyclic = gpu.gpu_deconvolve(psi0, h)
-    monkeypatch.setenv("MVN_PAD_MODE", "zero")
-    padded = gpu.gpu_deconvolve(psi0, h)
-    monkeypatch.delenv("MVN_PAD_MODE")
+    cyclic = gpu.gpu_deconvolve(psi0, h)  # pad_mode="none", the CPU path's policy
+    padded = gpu.gpu_deconvolve(psi0, h, pad_mode="zero_exact")  # exactly image + kernel - 1
     ref = _zero_padd_reference(orc, psi0, views, k1, k2, w, 0.006, 1e-4, 3)
     assert np.abs(padded - ref).max() <= 1e-4 * np.abs(ref).max()
     assert np.abs(padded - cyclic).max() > 1e-3 * np.abs(ref).max()  # the two policies do differ
+    # the same selection through the environment (what round 1 offered), the setter left alone
+    monkeypatch.setenv("MVN_PAD_MODE", "zero_exact")
+    assert np.array_equal(gpu.gpu_deconvolve(psi0, h, pad_mode=False), padded)
+    monkeypatch.setenv("MVN_PAD_MODE", "none")
+    assert np.array_equal(gpu.gpu_deconvolve(psi0, h, pad_mode=False), cyclic)
+    monkeypatch.delenv("MVN_PAD_MODE")
 
 
 def test_zero_padd_good_size_mode(gpu, orc, monkeypatch):
-    # MVN_PAD_GOOD_SIZE=1: padded extents grow to 2^a 3^b 5^c 7^d (here 19+5-1=23 -> 24,
+    # The library's DEFAULT policy (the reference GPU entry's zero_padd, src/multiviewnative.cu:
+    # 26-27,128) with FFT-friendly padded extents: they grow to 2^a 3^b 5^c 7^d (here 19+5-1=23 -> 24,
     # 13+3-1=15, 17+7-1=23 -> 24) and the quotient is guarded where the view is exactly 0.
     # Delta PSFs make the blurred estimate EXACTLY 0 in the border: without the guard -> NaN.
     shape = (19, 13, 17)
@@ -543,11 +548,10 @@ def test_zero_padd_good_size_mode(gpu, orc, monkeypatch):
     k2 = [np.ascontiguousarray(k) for k in k2]
     psi0 = np.full(shape, 3.0, np.float32)
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
-    monkeypatch.setenv("MVN_PAD_MODE", "zero")
-    monkeypatch.setenv("MVN_PAD_GOOD_SIZE", "1")
-    got = gpu.gpu_deconvolve(psi0, h)
-    monkeypatch.delenv("MVN_PAD_MODE")
-    monkeypatch.delenv("MVN_PAD_GOOD_SIZE")
+    monkeypatch.delenv("MVN_PAD_MODE", raising=False)
+    monkeypatch.delenv("MVN_PAD_GOOD_SIZE", raising=False)
+    got = gpu.gpu_deconvolve(psi0, h, pad_mode=False)  # no setter, no environment: the default
+    assert np.array_equal(got, gpu.gpu_deconvolve(psi0, h, pad_mode="zero"))
     assert np.isfinite(got).all()
     # oracle on hand-padded stacks of the same good size, same guard
     ext, off = (24, 15, 24), (2, 1, 3)
@@ -581,11 +585,13 @@ def test_concurrent_abi_calls_are_serialised_per_device(gpu, orc):
     out = [None] * len(cases)
 
     def work(i):
-        out[i] = gpu.gpu_deconvolve(cases[i][1], cases[i][0])
+        out[i] = gpu.gpu_deconvolve(cases[i][1], cases[i][0], pad_mode=False)
 
+    gpu.set_pad_mode("none")  # process-wide: set once around the concurrent callers
     threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
     [t.start() for t in threads]
     [t.join() for t in threads]
+    gpu.set_pad_mode(None)
     for i, (h, psi0) in enumerate(cases):
         mx, rms = rel_err(out[i], orc.cpu_deconvolve(psi0, h, 4))
         assert mx <= MAX_REL and rms <= RMS_REL

@@ -222,6 +222,11 @@ def main():
                     help="skip ms_per_fft, the one-view parity check and the ABI end-to-end call "
                          "(keeps rocprof --stats averages clean)")
     ap.add_argument("--no-abi", action="store_true", help="skip the ABI end-to-end call")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one rank that still goes through torch.distributed and the chunked all-reduce "
+                         "(rehearses the N > 1 code path, stream ordering included, on a one-GPU box)")
+    ap.add_argument("--check-parity", action="store_true",
+                    help="N > 1: rank 0 still runs the one-view parity check / CPU sample (default: N = 1 only)")
     ap.add_argument("--dump-psi", default=None, help="rank 0 saves the final psi here (.npy)")
     args = ap.parse_args()
 
@@ -237,10 +242,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(world_env or "1")
     args.gpus = world
+    if args.force_dist and world_env is None:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(free_port()))
+    use_dist = world > 1 or args.force_dist
 
     dist = None
     torch = None
-    if world > 1:
+    if use_dist:
         # torch first: the product library then binds to the HIP runtime torch already loaded
         import torch
         import torch.distributed as dist
@@ -269,13 +278,13 @@ def main():
 
     driver = None
     delta = None
-    if world > 1:
+    if use_dist:
         nfl = eng.psi_ptr()[1]
         dev = torch.device("cuda", local_rank)
         delta = torch.zeros(nfl, dtype=torch.float32, device=dev)
         eng.bind_delta(delta.data_ptr())
         ext = None if args.host_sync else torch.cuda.ExternalStream(eng.stream(), device=dev)
-        driver = SimultaneousDriver(eng, delta, dist, chunks=args.chunks, stream=ext)
+        driver = SimultaneousDriver(eng, delta, dist, chunks=args.chunks, stream=ext, force_collective=args.force_dist)
     elif args.simultaneous:
         driver = SimultaneousDriver(eng, None, None)
 
@@ -287,12 +296,12 @@ def main():
 
     def fence():
         eng.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world > 1:
+    if use_dist:
         # communicator set-up (lazy in RCCL) must never land in the timed region, even with --warmup 0
         dist.all_reduce(delta, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
@@ -312,7 +321,7 @@ def main():
     prof = eng.profile_read() if not args.no_profile else {}
     eng.profile(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -355,7 +364,7 @@ def main():
         parts = [len(view_partition(V, world, r)) for r in range(world)]
         if driver is None:
             mode = "sequential (reference order, Gauss-Seidel)"
-        elif world == 1:
+        elif not use_dist:
             mode = "simultaneous (Jacobi), single rank"
         else:
             mode = "simultaneous (Jacobi): views sharded over ranks + 1 all-reduce of the psi-sized delta per " \
@@ -390,11 +399,11 @@ def main():
             actual = 22.0 * vol * V / (ms_per_step * 1e-3) / 1e9
             out["whole_step_GBps_actual_22vol"] = round(actual, 1)
             out["whole_step_actual_frac_of_8TBps"] = round(actual / HBM_PEAK_GBS, 4)
-    if world > 1:
+    if use_dist:
         eng.bind_delta(None)
     eng.close()
 
-    if rank == 0 and not args.no_side:
+    if rank == 0 and not args.no_side and (world == 1 or args.check_parity):
         try:
             if world == 1:
                 out["ms_per_fft"] = round(lib.fft3_time(shape, 0, 10, device=local_rank), 4)
@@ -411,7 +420,7 @@ def main():
                 }
         except Exception as e:  # the headline number must survive a failing side measurement
             out["side_measurement_error"] = "%s: %s" % (type(e).__name__, e)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

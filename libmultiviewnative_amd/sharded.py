@@ -82,12 +82,15 @@ class SimultaneousDriver:
     :class:`_Ordering`.
     """
 
-    def __init__(self, engine, delta, dist=None, after_collective=None, chunks=4, stream=None):
+    def __init__(self, engine, delta, dist=None, after_collective=None, chunks=4, stream=None,
+                 force_collective=False):
         self.engine = engine
         self.delta = delta
         self.dist = dist
         self.order = _Ordering(engine, stream, after_collective)
-        self.multi = dist is not None and dist.get_world_size() > 1
+        # force_collective: issue the (trivial) all-reduce even on one rank -- rehearsals of the
+        # multi-rank code path on a one-GPU box
+        self.multi = dist is not None and (dist.get_world_size() > 1 or force_collective)
         self.n = engine.delta_chunks(chunks if self.multi else 1)
         self.parts = []
         if self.multi:

@@ -122,3 +122,49 @@ def realistic_views(shape, n_views, kshape=(7, 7, 7), seed=42, n_blobs=12):
         ws.append(np.full(shape, 1.0 / n_views, np.float32))
     psi0 = np.full(shape, np.float32(views[0].mean()), np.float32)
     return truth.astype(np.float32), views, k1s, k2s, ws, psi0
+
+
+def structured_views(shape, n_views, kshape, seed=7, terms=4):
+    """Cheap non-trivial stacks for FULL-SIZE parity cases (512^3 and up, where realistic_views'
+    float64 meshgrids are too heavy): a few separable Gaussian blobs on a background of 10 plus a
+    little noise, so that every voxel differs and every spectral bin is populated.  One shared
+    weights array (1 / n_views).  Returns views, kernels1, kernels2, weights, psi0."""
+    rng = np.random.default_rng(seed)
+    ax = [np.arange(s, dtype=np.float32) for s in shape]
+    views, k1s, k2s = [], [], []
+    for v in range(n_views):
+        acc = rng.random(shape, dtype=np.float32)
+        acc *= np.float32(2.0)
+        acc += np.float32(10.0)
+        for _ in range(terms):
+            f = [np.exp(-0.5 * ((a - np.float32(rng.uniform(0.1 * s, 0.9 * s))) /
+                                np.float32(rng.uniform(2.0, max(2.5, 0.12 * s)))) ** 2).astype(np.float32)
+                 for a, s in zip(ax, shape)]
+            plane = (np.float32(rng.uniform(50, 400)) * f[1])[:, None] * f[2][None, :]
+            acc += f[0][:, None, None] * plane[None, :, :]
+        views.append(acc)
+        sig = [1.5, 1.5, 1.5]
+        sig[v % 3] = 3.0
+        psf = gaussian_psf(tuple(min(k, s) for k, s in zip(kshape, shape)), sig)
+        k1s.append(psf)
+        k2s.append(np.ascontiguousarray(psf[::-1, ::-1, ::-1]))
+    w = np.full(shape, 1.0 / n_views, np.float32)
+    psi0 = np.full(shape, np.float32(views[0].mean()), np.float32)
+    return views, k1s, k2s, [w] * n_views, psi0
+
+
+def expected_good_extent(binding, n, last_axis):
+    """The padded extent the ABI call picks for one axis (mvn_abi.cpp good_extent): the cheapest
+    2^a 3^b 5^c 7^d length in [n, 1.3 n + 8], fixed-kernel lengths priced 1, others 1.45."""
+    def smooth(c):
+        for p in (2, 3, 5, 7):
+            while c % p == 0:
+                c //= p
+        return c == 1
+
+    def fixed(c):
+        info = binding.plan_describe((8, 8, c) if last_axis else (c, 8, 8))
+        return bool(info["fx_rows"] if last_axis else info["fx_ax0"])
+
+    cand = [c for c in range(n, n + n * 3 // 10 + 9) if smooth(c)]
+    return min(cand, key=lambda c: (c * (1.0 if fixed(c) else 1.45), c))

@@ -599,3 +599,41 @@ def test_memory_heuristic_counts_the_cached_engine(tmp_path):
     # engine is already resident, nor count a stale engine that is about to be freed
     r = _run_cache_child("memory", {"MVN_EMU_TOTAL_MB": "16"}, tmp_path)
     assert "memory constraints" in r.stderr
+
+
+def test_default_padding_policy_on_a_block(emu):
+    # the library default (zero_padd with FFT-friendly extents, stacks embedded / cropped by
+    # strided device copies): oracle on hand-padded stacks of the same extents, guard on
+    from ref_fixtures import expected_good_extent
+    shape = (20, 18, 22)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 5, 5), seed=2)
+    k2 = [np.ascontiguousarray(k[1:4, 1:4, 1:4]) for k in k2]
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    emu.l.mvn_release_cached_engines()
+    got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert got.shape == shape and np.isfinite(got).all()
+    ext = [expected_good_extent(emu, n + 4, d == 2) for d, n in enumerate(shape)]
+    sl = tuple(slice(2, 2 + s) for s in shape)
+
+    def embed(x):
+        out = np.zeros(ext, np.float32)
+        out[sl] = x
+        return out
+
+    hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-4, 3)
+    orc.set_quotient_guard(True)
+    try:
+        ref = orc.cpu_deconvolve(embed(psi0), hp, 4)[sl]
+    finally:
+        orc.set_quotient_guard(False)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), ext
+    # a second block of the same shape re-uses the cached (padded) engine; then a dense call of the
+    # padded shape itself must not see stale padding state
+    again = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert np.array_equal(again, got)
+    dense = emu.gpu_deconvolve(embed(psi0), hp, pad_mode="none")[sl]
+    orc_dense = orc.cpu_deconvolve(embed(psi0), hp, 4)[sl]
+    assert np.abs(dense - orc_dense).max() <= 1e-4 * np.abs(orc_dense).max()
+    third = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert np.array_equal(third, got)
+    emu.l.mvn_release_cached_engines()

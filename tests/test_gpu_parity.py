@@ -756,6 +756,11 @@ def test_slab_engine_one_rank_equals_resident_engine(gpu, shape, V):
     e.close()
     assert np.all(np.isfinite(got))
     assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+    # and against the CPU oracle of the reference's loop, not only against the resident engine
+    from oracle import binding as orc
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, its)
+    mx, rms = rel_err(got, orc.cpu_deconvolve(psi0, h, 4))
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
 
 
 _GRAPH_CHILD = r"""
@@ -820,3 +825,225 @@ def test_long_lines_use_the_split_window_kernels(gpu):
         ref = np.fft.rfftn(x.astype(np.float64))
         assert np.abs(spec - ref).max() <= 2e-6 * np.abs(ref).max()
         assert np.abs(y / x.size - x).max() <= 1e-5
+
+
+# ---- round 2: non-trivial data on the HEADLINE kernel instantiations, BASELINE configs[3] / [4] ----
+@pytest.mark.parametrize("lam", [0.0, 0.006])
+@pytest.mark.parametrize("shape", [(512, 32, 64), (512, 64, 512)])
+def test_headline_instantiations_vs_oracle(gpu, orc, shape, lam):
+    # kx_strided<512, FWD_MUL_INV> (the LDS-fused dim0 body: the bench's dominant kernel),
+    # kx_strided<512, *> and, for d2 = 512, kx_rows_c2r_r2c<256, DIVIDE / UPDATE>, on blobs + PSFs
+    info = gpu.plan_describe(shape)
+    assert info["fx_ax0"] == 1 and info["fx_rows"] == 1
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (9, 7, 11), seed=3)
+    h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 2)
+    got = gpu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, -1)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+    assert float(((got.astype(np.float64) - ref) ** 2).sum()) < 1  # tests/test_gpu_deconvolve_impl.cu:200
+
+
+def test_full_size_512_six_views_vs_oracle(gpu, orc):
+    # BASELINE.json configs[2] at FULL size on non-trivial data: 512^3, 6 views, 31^3 PSFs, one
+    # sequential sweep through the resident engine vs the oracle (about half a minute of CPU)
+    from ref_fixtures import structured_views
+    shape, V = (512, 512, 512), 6
+    views, k1, k2, w, psi0 = structured_views(shape, V, (31, 31, 31))
+    eng = gpu.engine(shape, V)
+    for v in range(V):
+        eng.set_view(v, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    eng.iterate(1, 0.006, 1e-4)
+    got = eng.get_psi()
+    eng.close()
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
+    ref = orc.cpu_deconvolve(psi0, h, -1)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+    assert np.abs(got - psi0).max() > 1e-2 * np.abs(psi0).max()  # the sweep did change psi
+
+
+def test_config3_eight_views_simultaneous_512_vs_oracle(gpu, orc):
+    # BASELINE.json configs[3] on ONE GPU: 512^3, 8 views, simultaneous (Jacobi) update -- what the 8
+    # ranks of the sharded run compute together -- in 4 dim0 chunks (the overlapped form), one
+    # iteration vs oracle_deconvolve_simultaneous
+    from ref_fixtures import structured_views
+    shape, V = (512, 512, 512), 8
+    views, k1, k2, w, psi0 = structured_views(shape, V, (31, 31, 31), seed=11, terms=3)
+    eng = gpu.engine(shape, V)
+    for v in range(V):
+        eng.set_view(v, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    n = eng.delta_chunks(4)
+    assert n == 4
+    eng.compute_delta_head(0.006, 1e-4)
+    for c in range(n):
+        eng.compute_delta_chunk(c, n)
+    for c in range(n):
+        eng.apply_delta_chunk(c, n, False)
+    got = eng.get_psi()
+    eng.close()
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, -1)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+
+
+def test_config4_long_line_kernels_vs_oracle(gpu, orc):
+    # BASELINE.json configs[4]'s kernels (1920-long lines on dim1, 960-bin last-axis tiles, the
+    # split-window passes) on non-trivial data: a 16-plane slab of the 320 x 1920 x 1920 shape
+    from ref_fixtures import structured_views
+    shape = (16, 1920, 1920)
+    info = gpu.plan_describe(shape)
+    assert info["fx_rows"] == 1 and info["fx_ax1"] == 1
+    views, k1, k2, w, psi0 = structured_views(shape, 1, (9, 31, 31), seed=5)
+    c0 = gpu.l.mvn_split_launch_count()
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    got = gpu.gpu_deconvolve(psi0, h)
+    assert gpu.l.mvn_split_launch_count() > c0
+    ref = orc.cpu_deconvolve(psi0, h, -1)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+
+
+@pytest.mark.parametrize("shape,chunks", [((64, 64, 64), 4), ((24, 20, 18), 3), ((12, 10, 9), 5)])
+def test_chunked_simultaneous_steps_vs_oracle(gpu, orc, shape, chunks):
+    # the overlapped form of the sharded step on one rank, several iterations with the spectrum of
+    # psi handed from apply_delta_chunk to the next compute_delta_head
+    from libmultiviewnative_amd.sharded import SimultaneousDriver
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 3, (5, 5, 5), seed=8)
+    eng = gpu.engine(shape, 3)
+    for v in range(3):
+        eng.set_view(v, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    n = eng.delta_chunks(chunks)
+    assert n >= 2
+    for it in range(3):
+        eng.compute_delta_head(0.006, 1e-4)
+        for c in range(n):
+            eng.compute_delta_chunk(c, n)
+        for c in range(n):
+            eng.apply_delta_chunk(c, n, it < 2)
+    got = eng.get_psi()
+    # and through the driver without a process group (one chunk, no collective)
+    eng.set_psi(psi0)
+    SimultaneousDriver(eng, None, None).run(3, 0.006, 1e-4)
+    again = eng.get_psi()
+    eng.close()
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
+    for x in (got, again):
+        mx, rms = rel_err(x, ref)
+        assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+    assert np.array_equal(got, again)  # same kernels on row / plane ranges
+
+
+def _bench_problem(shape, V, psf_edge):
+    import bench
+    views, k1, k2 = [], [], []
+    for v in range(V):
+        a, b, c = bench.make_view(shape, v, psf_edge)
+        views.append(a)
+        k1.append(b)
+        k2.append(c)
+    w = [np.full(shape, 1.0 / V, np.float32)] * V
+    psi0 = np.full(shape, np.float32(bench.start_value()), np.float32)
+    return views, k1, k2, w, psi0
+
+
+@pytest.mark.parametrize("launch", ["two_ranks_gloo", "one_rank_nccl", "two_ranks_gloo_hostsync"])
+def test_bench_multi_rank_launch_path_vs_oracle(gpu, orc, tmp_path, launch):
+    # `python bench.py --gpus 2 ...` exactly as typed (the parent spawns the ranks itself): 64^3, 3
+    # views split 2 + 1 over two ranks that share device 0 (gloo; RCCL refuses two ranks on one
+    # GPU), chunked all-reduce ordered by stream events / by host synchronisation; and the RCCL
+    # path on one rank (--force-dist).  Result vs oracle_deconvolve_simultaneous.
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "psi.npy")
+    shape, V, psf, its = (64, 64, 64), 3, 9, 3
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--size", "64", "64", "64", "--views", str(V),
+           "--psf", str(psf), "--steps", str(its), "--warmup", "0", "--no-side", "--no-profile", "--dump-psi", dump]
+    if launch == "one_rank_nccl":
+        cmd += ["--gpus", "1", "--force-dist", "--backend", "nccl"]
+    else:
+        cmd += ["--gpus", "2", "--backend", "gloo", "--all-ranks-on-device", "0"]
+        if launch.endswith("hostsync"):
+            cmd += ["--host-sync"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == (1 if launch == "one_rank_nccl" else 2) and out["scaling"] == "strong"
+    assert out["config"]["views_total"] == V and out["psi_finite_positive"]
+    if launch != "one_rank_nccl":
+        assert out["config"]["views_per_rank"] == [2, 1]
+    assert "Jacobi" in out["config"]["update_mode"]
+    got = np.load(dump)
+    views, k1, k2, w, psi0 = _bench_problem(shape, V, psf)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, its)
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+
+
+def test_psf_cache_invalidation_on_gpu(gpu, orc):
+    # SURVEY.md 8f row 3 on the device: block-after-block calls re-use the resident PSF spectra; the
+    # same shape with changed kernel bytes must prepare them again and give the oracle's result
+    shape = (32, 24, 40)
+    rng = np.random.default_rng(5)
+    _, views, k1, k2, w, _ = realistic_views(shape, 2, (5, 5, 5), seed=9)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+
+    def run(vs, a, b):
+        h = WorkspaceHolder(vs, a, b, w, lambda_=0.006, min_value=1e-4, iterations=2)
+        psi0 = np.full(shape, np.float32(vs[0].mean()), np.float32)
+        mx, rms = rel_err(gpu.gpu_deconvolve(psi0, h), orc.cpu_deconvolve(psi0, h, 2))
+        assert mx <= MAX_REL and rms <= RMS_REL
+
+    h0, m0 = gpu.psf_cache_counters()
+    run(views, k1, k2)
+    h1, m1 = gpu.psf_cache_counters()
+    assert (h1 - h0, m1 - m0) == (0, 4)
+    other = [(v * rng.uniform(0.5, 1.5, shape)).astype(np.float32) for v in views]
+    run(other, k1, k2)  # new stacks, same PSFs: every spectrum re-used
+    h2, m2 = gpu.psf_cache_counters()
+    assert (h2 - h1, m2 - m1) == (4, 0)
+    k1b = [k * np.float32(0.5) for k in k1]  # same shape, every kernel1 byte changed
+    run(other, k1b, k2)
+    h3, m3 = gpu.psf_cache_counters()
+    assert (h3 - h2, m3 - m2) == (2, 2)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+
+
+def test_default_padding_policy_on_a_block(gpu, orc):
+    # the library default (zero_padd with FFT-friendly extents): a 50 x 60 x 70 block with 9^3 / 7^3
+    # PSFs runs on a padded 64-ish volume and is cropped back; oracle on hand-padded stacks, guard on
+    shape = (50, 60, 70)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (9, 9, 9), seed=2)
+    k2 = [np.ascontiguousarray(k[1:8, 1:8, 1:8]) for k in k2]
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    got = gpu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert got.shape == shape and np.isfinite(got).all()
+    # image + kernel - 1 = (58, 68, 78) -> good extents; the offsets stay (kernel - 1) / 2 = 4
+    from ref_fixtures import expected_good_extent
+    ext = [expected_good_extent(gpu, n, d == 2) for d, n in enumerate((58, 68, 78))]
+    sl = tuple(slice(4, 4 + s) for s in shape)
+
+    def embed(x):
+        out = np.zeros(ext, np.float32)
+        out[sl] = x
+        return out
+
+    hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-4, 3)
+    orc.set_quotient_guard(True)
+    try:
+        ref = orc.cpu_deconvolve(embed(psi0), hp, 4)[sl]
+    finally:
+        orc.set_quotient_guard(False)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms, ext)

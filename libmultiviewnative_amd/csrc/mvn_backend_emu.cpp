@@ -21,6 +21,7 @@
 
 #include "mvn_backend.hpp"
 #include "mvn_fixed_geom.hpp"
+#include "mvn_wave_rows.hpp"
 
 namespace mvn {
 namespace be {
@@ -135,6 +136,43 @@ graph_exec_t capture_end(stream_t) { throw std::runtime_error("mvn: no graphs in
 void graph_launch(graph_exec_t, stream_t) { throw std::runtime_error("mvn: no graphs in the host emulation"); }
 void graph_destroy(graph_exec_t) {}
 
+// wave-row kernels (d2 = 512, mvn_wave_rows.hpp): a "grid" of about a third of the workgroups a
+// one-sweep launch would have, so that the sweep loop and its ragged tail are exercised
+static bool emu_wave_rows(const RowsParams& p) {
+  const char* e = std::getenv("MVN_NO_WAVE_ROWS");
+  return !(e && *e && std::strcmp(e, "0") != 0) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
+}
+
+template <int MODE, int EPI>
+static void emu_wave_rows_run(const RowsParams& p) {
+  typedef FxCtx<WrRegs, WrCfg::NT> Ctx;
+  const long pairs = (p.rows + 1) / 2;
+  const long full = (pairs + WrCfg::WAVES - 1) / WrCfg::WAVES;
+  const long grid = full > 2 ? (full + 2) / 3 : full;
+#pragma omp parallel
+  {
+    std::vector<char> lds(sizeof(cfloat) * WrCfg::lds_cfloats + 64);
+    std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+    for (long b = 0; b < grid; ++b) wr_rows_body<MODE, EPI>(p, b, grid, (cfloat*)lds.data(), *ctx);
+  }
+}
+
+template <int MODE>
+static void emu_wave_rows_mode(const RowsParams& p) {
+  switch (p.epi.mode) {
+    case MVN_EPI_DIVIDE: emu_wave_rows_run<MODE, MVN_EPI_DIVIDE>(p); break;
+    case MVN_EPI_UPDATE: emu_wave_rows_run<MODE, MVN_EPI_UPDATE>(p); break;
+    case MVN_EPI_DELTA:
+      if (MODE == MVN_WR_C2R) {
+        emu_wave_rows_run<MVN_WR_C2R, MVN_EPI_DELTA>(p);
+        break;
+      }
+      throw std::invalid_argument("mvn: DELTA epilogue only in the plain c2r pass");
+    default: emu_wave_rows_run<MODE, MVN_EPI_STORE>(p); break;
+  }
+}
+
 // fixed-length kernels: every phase is run for all thread ids in turn (real thread mapping)
 template <int H>
 static void emu_rows_fused(const RowsParams& p, long ntiles) {
@@ -156,6 +194,7 @@ static void emu_rows_fused(const RowsParams& p, long ntiles) {
 }
 
 void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int, size_t lds_bytes, stream_t) {
+  if (emu_wave_rows(p)) return emu_wave_rows_mode<MVN_WR_C2R_R2C>(p);
   if (!p.fixed) {  // run-time-radix form of the fused pass (any even d2)
 #pragma omp parallel
     {
@@ -285,6 +324,7 @@ static bool emu_strided_fixed_dispatch(int mode, const StridedParams& p, long nb
 
 void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
+  if (emu_wave_rows(p)) return emu_wave_rows_run<MVN_WR_R2C, MVN_EPI_STORE>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, true)) throw std::invalid_argument("mvn: no fixed kernel");
     return;
@@ -306,6 +346,7 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t ld
 
 void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
+  if (emu_wave_rows(p)) return emu_wave_rows_mode<MVN_WR_C2R>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, false)) throw std::invalid_argument("mvn: no fixed kernel");
     return;

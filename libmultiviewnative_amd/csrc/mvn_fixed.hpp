@@ -581,8 +581,10 @@ MVN_HD void fx_st_stage0_store(const StridedParams& P, long base, const cfloat* 
   }
 }
 
-// tiles first, first + step, ... < total
-template <int N, int MODE, typename Ctx>
+// tiles first, first + step, ... < total.  WALK = false: exactly one tile per workgroup (the launch
+// has one workgroup per tile), nothing is fetched ahead -- the fused pass then holds only its rows
+// and its PSF operands in registers.
+template <int N, int MODE, typename Ctx, bool WALK = true>
 MVN_HD void fx_strided_body(const StridedParams& P, long first, long total, long step, cfloat* lds,
                             Ctx& ctx) {
   typedef FxStridedCfg<N> C;
@@ -592,9 +594,9 @@ MVN_HD void fx_strided_body(const StridedParams& P, long first, long total, long
   cfloat* tws = lds + N * C::TP;
   if (first >= total) return;
   MVN_PHASE(ctx, (fx_st_prologue<N, MODE>(P, fx_st_base<N>(P, first), tws, r, tid)));
-  for (long block = first; block < total; block += step) {
+  for (long block = first; block < (WALK ? total : first + 1); block += step) {
     const long base = fx_st_base<N>(P, block);
-    const bool has_next = block + step < total;
+    const bool has_next = WALK && block + step < total;
     const long next_base = has_next ? fx_st_base<N>(P, block + step) : base;
     if (MODE == MVN_ST_INV) {
       MVN_PHASE(ctx, (fx_st_last_in<N>(P, next_base, has_next, buf, r, tid)));
@@ -626,7 +628,11 @@ MVN_HD void fx_strided_body(const StridedParams& P, long first, long total, long
 template <int N>
 struct FxFusedCfg {
   typedef FxStridedCfg<N> S;
+#ifdef MVN_FX_NO_LDS_FUSED
+  static constexpr bool USE = false;  // experiment: register-staged body for every length
+#else
   static constexpr bool USE = S::WG_PER_CU >= 2;
+#endif
   static constexpr int T = S::T, TP = S::TP, CH = S::CH;
   // threads: whole tile rows per sweep (N * CH divisible by NT), not more than one radix-8
   // butterfly each; 512 unless that leaves more than eight 16-byte loads per thread
@@ -931,7 +937,14 @@ MVN_HD void fx_strided_split_body(const StridedParams& P, long first, long total
 // which body, register block and workgroup size a (length, mode) pair uses
 template <int N, int MODE>
 struct FxStridedSel {
-  static constexpr bool LDS_FUSED = MODE == MVN_ST_FWD_MUL_INV && FxFusedCfg<N>::USE;
+  // the fused pass where two or more workgroups share a CU: 0 = every stage through the LDS with
+  // one column per work item (fx_fused_lds_body), 1 = outer stages in registers, one tile per
+  // workgroup (fx_strided_body<.., WALK = false>: half the LDS traffic, 16-byte LDS accesses)
+#ifndef MVN_FX_FUSED_VARIANT
+#define MVN_FX_FUSED_VARIANT 0
+#endif
+  static constexpr bool ONE_TILE = MODE == MVN_ST_FWD_MUL_INV && FxFusedCfg<N>::USE;
+  static constexpr bool LDS_FUSED = ONE_TILE && MVN_FX_FUSED_VARIANT == 0;
   static constexpr int NT = LDS_FUSED ? FxFusedCfg<N>::NT : FxStridedCfg<N>::NT;
   static constexpr int WAVES = LDS_FUSED ? FxFusedCfg<N>::WAVES : FxStridedCfg<N>::WAVES;
   typedef typename std::conditional<LDS_FUSED, FxFusedRegs<N>, FxStridedRegs<N>>::type Regs;
@@ -941,6 +954,9 @@ struct FxStridedSel {
     if constexpr (LDS_FUSED) {
       // launched one workgroup per tile (step == grid size == total)
       for (long block = first; block < total; block += step) fx_fused_lds_body<N>(P, block, lds, ctx);
+    } else if constexpr (ONE_TILE) {
+      for (long block = first; block < total; block += step)
+        fx_strided_body<N, MODE, Ctx, false>(P, block, total, step, lds, ctx);
     } else
       fx_strided_body<N, MODE>(P, first, total, step, lds, ctx);
   }
@@ -1256,11 +1272,15 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
+#ifndef MVN_EXP_SKIP_PREPOST  // timing experiment only (wrong results): what two LDS round trips cost
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
+#endif
   fx_dit<H, T, TP, C::PAD, NT, +1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, true, EPI>(P, r0, buf, tws, r, tid)));
   fx_dif<H, T, TP, C::PAD, NT, -1, 1>(buf, tws, ctx);
+#ifndef MVN_EXP_SKIP_PREPOST
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
+#endif
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
 

@@ -31,6 +31,7 @@
 
 #include "mvn_backend.hpp"
 #include "mvn_fixed_geom.hpp"
+#include "mvn_wave_rows.hpp"
 
 #define HIP_CHECK(expr)                                                                      \
   do {                                                                                       \
@@ -100,6 +101,16 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsPa
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
   fx_rows_c2r_r2c_body<H, EPI>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+}
+
+// last-axis passes for d2 = 512 in which a row never leaves its half-wave (mvn_wave_rows.hpp): no
+// workgroup barrier inside the loop over rows, 4 LDS exchanges per fused pass
+template <int MODE, int EPI>
+__global__ void __launch_bounds__(WrCfg::NT, 4) kw_rows(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<WrRegs, WrCfg::NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  wr_rows_body<MODE, EPI>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
 template <int N, int MODE>
@@ -415,6 +426,33 @@ static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads
   HIP_CHECK(hipGetLastError());
 }
 
+// wave-row kernels (d2 = 512): workgroups sweep over the row pairs, the grid is what the device
+// holds at once.  MVN_NO_WAVE_ROWS=1 keeps the tiled kernels of mvn_fixed.hpp; MVN_WAVE_ROWS_MASK
+// selects the passes that use them: 1 plain r2c, 2 plain c2r, 4 fused divide, 8 fused update / store.
+static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
+  static const bool off = [] {
+    const char* e = std::getenv("MVN_NO_WAVE_ROWS");
+    return e && *e && std::strcmp(e, "0") != 0;
+  }();
+  static const int mask = [] {
+    const char* e = std::getenv("MVN_WAVE_ROWS_MASK");
+    return e && *e ? std::atoi(e) : 15;
+  }();
+  return !off && (mask & kind_bit) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
+}
+
+template <typename K>
+static void launch_wave_rows(K kernel, const RowsParams& p, stream_t s) {
+  const size_t lds = sizeof(cfloat) * (size_t)WrCfg::lds_cfloats;
+  const long pairs = (p.rows + 1) / 2;
+  long grid = (pairs + WrCfg::WAVES - 1) / WrCfg::WAVES;
+  const long resident = (long)resident_per_cu(reinterpret_cast<const void*>(kernel), WrCfg::NT, lds) *
+                        device_cu_count();
+  if (grid > resident) grid = resident;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WrCfg::NT), lds, hs(s), p);
+  HIP_CHECK(hipGetLastError());
+}
+
 #define MVN_DISPATCH_T(T_, KERNEL_EXPR)                                        \
   switch (T_) {                                                                \
     case 16: { constexpr int TT = 16; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break; \
@@ -435,6 +473,7 @@ void launch_rows_r2c(const RowsParams& p, bool even, long nblocks, int nthreads,
   if (p.fixed) {
     check_aligned16(p.in_real, "input");
     check_aligned16(p.out_cplx, "output");
+    if (wave_rows_enabled(p, 1)) return launch_wave_rows(kw_rows<MVN_WR_R2C, MVN_EPI_STORE>, p, s);
     switch (p.h) {
 #define X(H) case H: launch_pass(kx_rows_r2c<H>, p, nblocks, nthreads, lds_bytes, s); return;
       MVN_FIXED_ROWS_LENGTHS(X)
@@ -455,6 +494,14 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
   if (p.fixed) {
     check_aligned16(p.in_cplx, "input");
     check_aligned16(p.out_real, "output");
+    if (wave_rows_enabled(p, 2)) {
+      switch (p.epi.mode) {
+        case MVN_EPI_DIVIDE: return launch_wave_rows(kw_rows<MVN_WR_C2R, MVN_EPI_DIVIDE>, p, s);
+        case MVN_EPI_UPDATE: return launch_wave_rows(kw_rows<MVN_WR_C2R, MVN_EPI_UPDATE>, p, s);
+        case MVN_EPI_DELTA: return launch_wave_rows(kw_rows<MVN_WR_C2R, MVN_EPI_DELTA>, p, s);
+        default: return launch_wave_rows(kw_rows<MVN_WR_C2R, MVN_EPI_STORE>, p, s);
+      }
+    }
     switch (p.h) {
 #define X(H)                                                                                  \
   case H:                                                                                     \
@@ -486,6 +533,13 @@ void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t
   }
   check_aligned16(p.in_cplx, "input");
   check_aligned16(p.out_cplx, "output");
+  if (wave_rows_enabled(p, p.epi.mode == MVN_EPI_DIVIDE ? 4 : 8)) {
+    switch (p.epi.mode) {
+      case MVN_EPI_DIVIDE: return launch_wave_rows(kw_rows<MVN_WR_C2R_R2C, MVN_EPI_DIVIDE>, p, s);
+      case MVN_EPI_UPDATE: return launch_wave_rows(kw_rows<MVN_WR_C2R_R2C, MVN_EPI_UPDATE>, p, s);
+      default: return launch_wave_rows(kw_rows<MVN_WR_C2R_R2C, MVN_EPI_STORE>, p, s);
+    }
+  }
   switch (p.h) {
 #define X(H)                                                                                  \
   case H:                                                                                     \
@@ -552,7 +606,7 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
     if (try_launch_split<N>(mode, p, nblocks, s)) return;                                          \
     if (mode == MVN_ST_FWD) launch_walking(kx_strided<N, MVN_ST_FWD>, p, nblocks, FxStridedSel<N, MVN_ST_FWD>::NT, lds_bytes, s, true); \
     else if (mode == MVN_ST_INV) launch_walking(kx_strided<N, MVN_ST_INV>, p, nblocks, FxStridedSel<N, MVN_ST_INV>::NT, lds_bytes, s, true); \
-    else launch_walking(kx_strided<N, MVN_ST_FWD_MUL_INV>, p, nblocks, FxStridedSel<N, MVN_ST_FWD_MUL_INV>::NT, lds_bytes, s, !FxStridedSel<N, MVN_ST_FWD_MUL_INV>::LDS_FUSED); \
+    else launch_walking(kx_strided<N, MVN_ST_FWD_MUL_INV>, p, nblocks, FxStridedSel<N, MVN_ST_FWD_MUL_INV>::NT, lds_bytes, s, !FxStridedSel<N, MVN_ST_FWD_MUL_INV>::ONE_TILE); \
     return;
       MVN_FIXED_STRIDED_LENGTHS(X)
 #undef X

@@ -138,9 +138,14 @@ void graph_destroy(graph_exec_t) {}
 
 // wave-row kernels (d2 = 512, mvn_wave_rows.hpp): a "grid" of about a third of the workgroups a
 // one-sweep launch would have, so that the sweep loop and its ragged tail are exercised
-static bool emu_wave_rows(const RowsParams& p) {
+// same knobs as the HIP backend, but read at every launch and with every pass enabled by default
+// (the emulation exists to test them)
+static bool emu_wave_rows(const RowsParams& p, int kind_bit) {
   const char* e = std::getenv("MVN_NO_WAVE_ROWS");
-  return !(e && *e && std::strcmp(e, "0") != 0) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
+  const char* m = std::getenv("MVN_WAVE_ROWS_MASK");
+  const int mask = m && *m ? std::atoi(m) : 15;
+  return !(e && *e && std::strcmp(e, "0") != 0) && (mask & kind_bit) && p.fixed && p.h == WrCfg::H &&
+         p.C == WrCfg::H;
 }
 
 template <int MODE, int EPI>
@@ -194,7 +199,7 @@ static void emu_rows_fused(const RowsParams& p, long ntiles) {
 }
 
 void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int, size_t lds_bytes, stream_t) {
-  if (emu_wave_rows(p)) return emu_wave_rows_mode<MVN_WR_C2R_R2C>(p);
+  if (emu_wave_rows(p, p.epi.mode == MVN_EPI_DIVIDE ? 4 : 8)) return emu_wave_rows_mode<MVN_WR_C2R_R2C>(p);
   if (!p.fixed) {  // run-time-radix form of the fused pass (any even d2)
 #pragma omp parallel
     {
@@ -324,7 +329,7 @@ static bool emu_strided_fixed_dispatch(int mode, const StridedParams& p, long nb
 
 void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
-  if (emu_wave_rows(p)) return emu_wave_rows_run<MVN_WR_R2C, MVN_EPI_STORE>(p);
+  if (emu_wave_rows(p, 1)) return emu_wave_rows_run<MVN_WR_R2C, MVN_EPI_STORE>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, true)) throw std::invalid_argument("mvn: no fixed kernel");
     return;
@@ -346,7 +351,7 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t ld
 
 void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
-  if (emu_wave_rows(p)) return emu_wave_rows_mode<MVN_WR_C2R>(p);
+  if (emu_wave_rows(p, 2)) return emu_wave_rows_mode<MVN_WR_C2R>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, false)) throw std::invalid_argument("mvn: no fixed kernel");
     return;

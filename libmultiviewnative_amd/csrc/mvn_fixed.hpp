@@ -402,8 +402,12 @@ struct FxStagesQ {
 // the first inverse stage has been written to the LDS -- so they are in flight during the LDS
 // stages and the stores of the current tile (fused pass: see fx_st_first).
 
+#ifndef MVN_PROBE_BLOCK
+#define MVN_PROBE_BLOCK(b) (b)  // timing probes only (mvn_kernels.hip, -DMVN_PROBE): re-use a few tiles
+#endif
 template <int N>
 MVN_HD long fx_st_base(const StridedParams& P, long block) {
+  block = MVN_PROBE_BLOCK(block);
   // launches have far fewer than 2^31 tiles (checked by the launcher): 32-bit division
   const unsigned o = (unsigned)block / (unsigned)P.tiles_per_outer;
   const unsigned t = (unsigned)block - o * (unsigned)P.tiles_per_outer;

@@ -29,6 +29,17 @@
 #include <stdexcept>
 #include <string>
 
+#ifdef MVN_PROBE
+// Timing probe (never in the product build): every workgroup works on tile (index mod wrap), so the
+// working set of a pass is a few MB that stay in the L2 / Infinity Cache -- what a pass costs when
+// HBM is out of the picture.  Results are garbage.  MVN_PROBE_WRAP_ST / MVN_PROBE_WRAP_ROWS = tiles.
+__device__ int g_probe_wrap_st = 0;
+__device__ int g_probe_wrap_rows = 0;
+#define MVN_PROBE_BLOCK(b) (g_probe_wrap_st > 0 ? (b) % g_probe_wrap_st : (b))
+#define MVN_PROBE_TILE(t) (g_probe_wrap_rows > 0 ? (t) % g_probe_wrap_rows : (t))
+#else
+#define MVN_PROBE_TILE(t) (t)
+#endif
 #include "mvn_backend.hpp"
 #include "mvn_fixed_geom.hpp"
 #include "mvn_wave_rows.hpp"
@@ -100,7 +111,7 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsPa
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_c2r_r2c_body<H, EPI>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_c2r_r2c_body<H, EPI>(p, (long)MVN_PROBE_TILE(blockIdx.x), (cfloat*)mvn_smem, ctx);
 }
 
 // last-axis passes for d2 = 512 in which a row never leaves its half-wave (mvn_wave_rows.hpp): no
@@ -351,7 +362,24 @@ static void ensure_lds(K kernel, size_t lds_bytes) {
   done[key] = lds_bytes;
 }
 
+#ifdef MVN_PROBE
+static void probe_setup() {
+  static const bool once = [] {
+    const char* a = std::getenv("MVN_PROBE_WRAP_ST");
+    const char* b = std::getenv("MVN_PROBE_WRAP_ROWS");
+    int va = a ? std::atoi(a) : 0, vb = b ? std::atoi(b) : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_wrap_st), &va, sizeof(int));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_wrap_rows), &vb, sizeof(int));
+    return true;
+  }();
+  (void)once;
+}
+#else
+static void probe_setup() {}
+#endif
+
 static void check_launch(long nblocks, int nthreads, size_t lds_bytes) {
+  probe_setup();
   if (nblocks < 1 || nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
   if (nthreads < 64 || nthreads > 1024 || nthreads % 64) throw std::invalid_argument("mvn: bad block size");
   if (lds_bytes > 160 * 1024) throw std::invalid_argument("mvn: LDS request exceeds 160 KiB");
@@ -427,8 +455,12 @@ static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads
 }
 
 // wave-row kernels (d2 = 512): workgroups sweep over the row pairs, the grid is what the device
-// holds at once.  MVN_NO_WAVE_ROWS=1 keeps the tiled kernels of mvn_fixed.hpp; MVN_WAVE_ROWS_MASK
-// selects the passes that use them: 1 plain r2c, 2 plain c2r, 4 fused divide, 8 fused update / store.
+// holds at once.  MVN_WAVE_ROWS_MASK selects the passes that use them (1 plain r2c, 2 plain c2r,
+// 4 fused divide, 8 fused update / store); MVN_NO_WAVE_ROWS=1 = mask 0.  Default 4: measured at
+// 512^3 on MI355X (bench.py, same box) the fused divide gains 4 % (0.347 -> 0.333 ms), the fused
+// update is even and the plain r2c / c2r passes, which the tiled kernels already run at the
+// streaming ceiling, lose 5-10 %; from L2-resident data (timing probe) the wave-row forms are
+// 12-14 % faster than the tiled ones, i.e. the difference is hidden behind HBM.
 static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
   static const bool off = [] {
     const char* e = std::getenv("MVN_NO_WAVE_ROWS");
@@ -436,14 +468,18 @@ static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
   }();
   static const int mask = [] {
     const char* e = std::getenv("MVN_WAVE_ROWS_MASK");
-    return e && *e ? std::atoi(e) : 15;
+    return e && *e ? std::atoi(e) : 4;
   }();
   return !off && (mask & kind_bit) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
 }
 
 template <typename K>
 static void launch_wave_rows(K kernel, const RowsParams& p, stream_t s) {
-  const size_t lds = sizeof(cfloat) * (size_t)WrCfg::lds_cfloats;
+  static const size_t pad = [] {  // experiment knob: extra LDS per workgroup = fewer resident workgroups
+    const char* e = std::getenv("MVN_WR_LDS_PAD_KB");
+    return (size_t)(e && *e ? std::atoi(e) : 0) * 1024;
+  }();
+  const size_t lds = sizeof(cfloat) * (size_t)WrCfg::lds_cfloats + pad;
   const long pairs = (p.rows + 1) / 2;
   long grid = (pairs + WrCfg::WAVES - 1) / WrCfg::WAVES;
   const long resident = (long)resident_per_cu(reinterpret_cast<const void*>(kernel), WrCfg::NT, lds) *

@@ -126,9 +126,12 @@ MVN_HD void wr_post_pair(cfloat& zk, cfloat& zm, cfloat w) {
 
 // row of lane `tid` in sweep `it` of workgroup `block` (two rows per wave: one per half-wave);
 // consecutive waves take consecutive row pairs
+#ifndef MVN_PROBE_TILE
+#define MVN_PROBE_TILE(t) (t)  // timing probes only (mvn_kernels.hip, -DMVN_PROBE)
+#endif
 MVN_HD long wr_row(long block, long nblocks, long it, int tid) {
   const long pair = (it * nblocks + block) * WrCfg::WAVES + (tid >> 6);
-  return 2 * pair + ((tid >> 5) & 1);
+  return 2 * (long)MVN_PROBE_TILE(pair) + ((tid >> 5) & 1);
 }
 
 MVN_HD cfloat* wr_buf(cfloat* rows, int tid) { return rows + (tid >> 5) * WrCfg::RB; }

@@ -637,3 +637,36 @@ def test_default_padding_policy_on_a_block(emu):
     third = emu.gpu_deconvolve(psi0, h, pad_mode=False)
     assert np.array_equal(third, got)
     emu.l.mvn_release_cached_engines()
+
+
+@pytest.mark.parametrize("mask", ["15", "4", "0"])
+def test_wave_row_kernels_d2_512(emu, monkeypatch, mask):
+    # d2 = 512: the last-axis passes in which a row never leaves its half-wave (mvn_wave_rows.hpp):
+    # every pass (mask 15), the product default (4: fused divide only), none (the tiled kernels)
+    monkeypatch.setenv("MVN_WAVE_ROWS_MASK", mask)
+    shape = (4, 12, 512)  # 48 rows = 24 row pairs: ragged last sweep of the emulation's small grid
+    assert emu.plan_describe(shape)["fx_rows"] == 1
+    x = np.random.default_rng(1).standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = emu.rfft3(x)
+    assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max()
+    back = emu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 2e-5
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (3, 5, 7), seed=3)
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+        got = emu.gpu_deconvolve(psi0, h)
+        ref = orc.cpu_deconvolve(psi0, h, 4)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    e = emu.engine(shape, 2)
+    for v in range(2):
+        e.set_view(v, views[v], w[v], k1[v], k2[v])
+    e.set_psi(psi0)
+    for _ in range(2):
+        e.compute_delta(0.006, 1e-4)
+        e.apply_delta()
+    got = e.get_psi()
+    e.close()
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()

@@ -414,9 +414,22 @@ void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler
   }
 }
 
+bool Plan3D::tiles_spectra() const {
+  static const bool off = env_int("MVN_NO_TILED_SPECTRA", 0) != 0;  // A/B knob
+  return fx_ax0 && !off;
+}
+
+void Plan3D::retile_spectrum(const cfloat* natural, cfloat* tiled, be::stream_t s) const {
+  const long cols = (long)L.d1 * L.C;
+  const int T = gx_ax0.T;
+  // tiled[(tile * d0 + row) * T + c] = natural[row * cols + tile * T + c], in floats for copy3d
+  be::launch_copy3d((float*)tiled, 2L * T, 2L * T * L.d0, (const float*)natural, 2L * cols, 2L * T, 2 * T,
+                    L.d0, (int)(cols / T), s);
+}
+
 void Plan3D::axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec,
                    const cfloat* spec_nyq, be::stream_t s, Profiler* prof, be::stream_t s_nyq,
-                   const cfloat* src, const cfloat* src_nyq) const {
+                   const cfloat* src, const cfloat* src_nyq, bool spec_tiled) const {
   if (!s_nyq) s_nyq = s;
   const int kind = mode == MVN_ST_FWD ? KK_AXIS0_FWD
                                       : (mode == MVN_ST_INV ? KK_AXIS0_INV : KK_AXIS0_FUSED);
@@ -428,6 +441,8 @@ void Plan3D::axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec,
     StridedParams p = make_strided(ax0, g, data, spec, 0, cols, 1, (int)cols);
     p.fixed = fx_ax0 ? 1 : 0;
     p.src = src;
+    if (spec_tiled && !fx_ax0) throw std::logic_error("mvn: tile-contiguous spectra need the fixed dim0 kernels");
+    p.spec_tiled = spec_tiled ? 1 : 0;
     ProfScope ps(prof, kind, s);
     be::launch_strided(mode, p, p.tiles_per_outer, g.threads, g.lds_bytes, s);
   }
@@ -459,14 +474,14 @@ void Plan3D::backward(float* vol, cfloat* nyq, float scale, be::stream_t s,
 
 void Plan3D::middle_passes(cfloat* work, cfloat* work_nyq, const cfloat* spec,
                            const cfloat* spec_nyq, be::stream_t s, Profiler* prof,
-                           SideStream* side) const {
+                           SideStream* side, bool spec_tiled) const {
   be::stream_t sn = s;
   if (side && side->s && L.even) {
     side->fork_from(s);  // the plane was written by the last-axis pass just enqueued on s
     sn = side->s;
   }
   axis1(MVN_ST_FWD, work, work_nyq, s, prof, sn);
-  axis0(MVN_ST_FWD_MUL_INV, work, work_nyq, spec, spec_nyq, s, prof, sn);
+  axis0(MVN_ST_FWD_MUL_INV, work, work_nyq, spec, spec_nyq, s, prof, sn, nullptr, nullptr, spec_tiled);
   axis1(MVN_ST_INV, work, work_nyq, s, prof, sn);
   if (sn != s) side->join_into(s);  // the next last-axis pass on s reads the plane
 }
@@ -567,6 +582,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   be::dzero(work_, mb, stream_);
   if (plan_->nyq_bytes()) work_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
   views_.resize((size_t)num_views);
+  spec_tiled_ = plan_->tiles_spectra();
   for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);
 }
@@ -698,6 +714,16 @@ bool Engine::psf_resident(ViewSlot& s, int i, const float* kernel, const int* kd
   return false;
 }
 
+void Engine::make_spectrum(const float* d_kernel, const int* kdims, float scale, float* spec,
+                           cfloat* nyq, float* scratch, be::stream_t s) {
+  if (!spec_tiled_) {
+    plan_->psf_spectrum(d_kernel, kdims, scale, spec, nyq, s);
+    return;
+  }
+  plan_->psf_spectrum(d_kernel, kdims, scale, scratch, nyq, s);  // the Nyquist plane stays as it is
+  plan_->retile_spectrum((const cfloat*)scratch, (cfloat*)spec, s);
+}
+
 void Engine::set_view(int v, const float* image, const float* weights, const float* kernel1,
                       const int* k1dims, const float* kernel2, const int* k2dims) {
   if (v < 0 || v >= (int)views_.size()) throw std::out_of_range("mvn: view index");
@@ -717,7 +743,9 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
     float* dk = (float*)be::dmalloc(kb);
     be::h2d(dk, ks[i], kb, stream_);
     try {
-      plan_->psf_spectrum(dk, kd[i], scale, specs[i], nyqs[i], stream_);
+      // nothing else runs on this engine during a blocking set_view: the work volume is the scratch
+      work_has_psi_spectrum_ = false;
+      make_spectrum(dk, kd[i], scale, specs[i], nyqs[i], work_, stream_);
     } catch (...) {
       be::stream_sync(stream_);
       be::dfree(dk);
@@ -759,7 +787,16 @@ void Engine::stage_view(int v, const float* image, const float* weights, const f
     float* dk = (float*)be::dmalloc(kb);
     stage_scratch_.push_back(dk);  // freed in finish_staging(), after the stream has drained
     be::h2d(dk, ks[i], kb, upload_stream_);
-    plan_->psf_spectrum(dk, kd[i], scale, specs[i], nyqs[i], upload_stream_);
+    float* scratch = nullptr;
+    if (spec_tiled_) {  // the main thread iterates on the work volume meanwhile: own scratch, freed
+                        // with the other staging scratch once the upload stream has drained
+      if (!stage_spec_scratch_) {
+        stage_spec_scratch_ = (float*)be::dmalloc(plan_->main_bytes());
+        stage_scratch_.push_back(stage_spec_scratch_);
+      }
+      scratch = stage_spec_scratch_;
+    }
+    make_spectrum(dk, kd[i], scale, specs[i], nyqs[i], scratch, upload_stream_);
   }
   be::event_record(staged_ev_[(size_t)v], upload_stream_);
   s.set = true;
@@ -784,6 +821,7 @@ void Engine::finish_staging() {
   if (upload_stream_) be::stream_sync(upload_stream_);
   for (size_t i = 0; i < stage_scratch_.size(); ++i) be::dfree(stage_scratch_[i]);
   stage_scratch_.clear();
+  stage_spec_scratch_ = nullptr;
 }
 
 // main thread: block until the uploader has enqueued view v, then make the compute stream wait
@@ -864,7 +902,7 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   SideStream* side = no_side ? nullptr : &side_;
   if (!work_has_psi_spectrum_) P.rows_r2c(psi_, W, work_nyq_, stream_, prof);
   work_has_psi_spectrum_ = false;
-  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, side);
+  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, side, spec_tiled_);
   // view / blurred, handed to convolution 2 as its last-axis spectrum
   if (fuse) {
     P.rows_c2r_r2c(W, work_nyq_, e1, stream_, prof);
@@ -873,7 +911,7 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
     P.rows_r2c(work_, W, work_nyq_, stream_, prof);
   }
   // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
-  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof, side);
+  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof, side, spec_tiled_);
   if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
     P.rows_c2r_r2c(W, work_nyq_, e2, stream_, prof);
     work_has_psi_spectrum_ = true;
@@ -1047,7 +1085,7 @@ void Engine::compute_delta_head(double lambda, float min_value) {
     // chunk-fed spectrum of psi was written on the main stream)
     if (use_side) side_.fork_from(stream_);
     P.axis0(MVN_ST_FWD_MUL_INV, W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
-            (const cfloat*)psi_spec_, psi_spec_nyq_);
+            (const cfloat*)psi_spec_, psi_spec_nyq_, spec_tiled_);
     P.axis1(MVN_ST_INV, W, work_nyq_, stream_, prof, sn);
     if (use_side) side_.join_into(stream_);
     if (fuse) {
@@ -1057,7 +1095,7 @@ void Engine::compute_delta_head(double lambda, float min_value) {
       P.rows_r2c(work_, W, work_nyq_, stream_, prof);
     }
     P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof,
-                    use_side ? &side_ : nullptr);
+                    use_side ? &side_ : nullptr, spec_tiled_);
     if (v + 1 < V) {
       P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
     } else {  // the last view's final pass is launched chunk by chunk (compute_delta_chunk)

@@ -140,9 +140,16 @@ class Plan3D {
   void axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr,
              be::stream_t s_nyq = nullptr, int z0 = 0, int nz = -1) const;
   // `src` / `src_nyq` (optional) make the pass out of place: read there, write to data / nyq
+  // `spec_tiled`: the main-array spectrum is in the tile-contiguous layout of retile_spectrum()
   void axis0(int mode, cfloat* data, cfloat* nyq, const cfloat* spec, const cfloat* spec_nyq,
              be::stream_t s, Profiler* prof = nullptr, be::stream_t s_nyq = nullptr,
-             const cfloat* src = nullptr, const cfloat* src_nyq = nullptr) const;
+             const cfloat* src = nullptr, const cfloat* src_nyq = nullptr, bool spec_tiled = false) const;
+  // PSF spectra of a resident engine are kept TILE-CONTIGUOUS for the fused dim0 pass where that
+  // pass runs the fixed-length kernels: [tile][row][T columns] instead of [row][d1 * C columns], so
+  // that the operand fetch of a tile is one stream of d0 * T * 8 bytes (64 KB at 512^3) instead of d0
+  // row segments of 128 bytes, each on another 1 MB-strided page.
+  bool tiles_spectra() const;
+  void retile_spectrum(const cfloat* natural, cfloat* tiled, be::stream_t s) const;
 
   // whole transforms, un-normalised, in place on (vol, nyq)
   void forward(float* vol, cfloat* nyq, be::stream_t s, Profiler* prof = nullptr) const;
@@ -156,7 +163,7 @@ class Plan3D {
   // inverse); with `side` the Nyquist plane's three launches run on a second stream, forked
   // after and joined before the last-axis passes that produce / consume the plane
   void middle_passes(cfloat* work, cfloat* work_nyq, const cfloat* spec, const cfloat* spec_nyq,
-                     be::stream_t s, Profiler* prof, struct SideStream* side) const;
+                     be::stream_t s, Profiler* prof, struct SideStream* side, bool spec_tiled = false) const;
   // spectrum of a PSF: zero volume, centre->origin wrapped insert scaled by `scale`, forward FFT
   void psf_spectrum(const float* d_kernel, const int* kdims, float scale, float* spec_vol,
                     cfloat* spec_nyq, be::stream_t s) const;
@@ -289,6 +296,12 @@ class Engine {
   float* embed_scratch_ = nullptr;  // one dense host-shaped stack: H2D lands here, a strided device copy embeds it
   size_t host_floats() const { return (size_t)host_dims_[0] * host_dims_[1] * host_dims_[2]; }
   void alloc_view(ViewSlot& s);
+  // PSF spectrum of slot array `spec` from a device-resident kernel: forward transform, then (where
+  // the plan wants it) the tile-contiguous re-ordering through `scratch` (one volume)
+  void make_spectrum(const float* d_kernel, const int* kdims, float scale, float* spec, cfloat* nyq,
+                     float* scratch, be::stream_t s);
+  bool spec_tiled_ = false;
+  float* stage_spec_scratch_ = nullptr;  // owned by stage_scratch_
   void wait_staged(int v);
   int device_;
   std::shared_ptr<Plan3D> plan_;

@@ -414,6 +414,16 @@ MVN_HD long fx_st_base(const StridedParams& P, long block) {
   return (long)o * P.ostride + (long)t * FxStridedCfg<N>::T;
 }
 
+// where tile `block` finds its PSF-spectrum operands, and the distance between their rows
+template <int N>
+MVN_HD const cfloat* fx_spec_tile(const StridedParams& P, long block, long base) {
+  return P.spec_tiled ? P.spec + (long)MVN_PROBE_BLOCK(block) * ((long)N * FxStridedCfg<N>::T) : P.spec + base;
+}
+template <int N>
+MVN_HD long fx_spec_estride(const StridedParams& P) {
+  return P.spec_tiled ? (long)FxStridedCfg<N>::T : P.estride;
+}
+
 // tile rows with the mapping of stage 0: work item w = tid + it NT <-> rows j2 + k M0
 template <int N>
 MVN_HD void fx_st_fetch_first(const StridedParams& P, long base, FxStridedRegs<N>& r, int tid) {
@@ -433,19 +443,23 @@ MVN_HD void fx_st_fetch_first(const StridedParams& P, long base, FxStridedRegs<N
 // rows of `from` with the mapping of the last stage: thread <-> rows b R + k (clamped work items
 // are loaded but never used)
 template <int N>
-MVN_HD void fx_st_fetch_last(const cfloat* from, const StridedParams& P, long base, qfloat* dst,
-                             int tid) {
+MVN_HD void fx_st_fetch_last_at(const cfloat* tile, long estride, qfloat* dst, int tid) {
   typedef FxStridedCfg<N> C;
 #pragma unroll
   for (int it = 0; it < C::ITL; ++it) {
     int w = tid + it * C::NT;
     if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;
     const int b = w / C::CH, q = w % C::CH;
-    const cfloat* src = from + base + (long)(b * C::RL) * P.estride + 2 * q;
+    const cfloat* src = tile + (long)(b * C::RL) * estride + 2 * q;
 #pragma unroll
     for (int k = 0; k < C::RL; ++k)
-      dst[it * C::RL + k] = *reinterpret_cast<const qfloat*>(src + k * P.estride);
+      dst[it * C::RL + k] = *reinterpret_cast<const qfloat*>(src + k * estride);
   }
+}
+template <int N>
+MVN_HD void fx_st_fetch_last(const cfloat* from, const StridedParams& P, long base, qfloat* dst,
+                             int tid) {
+  fx_st_fetch_last_at<N>(from + base, P.estride, dst, tid);
 }
 
 // before the first tile: the twiddle table into the LDS, first tile's rows (and PSF operands)
@@ -466,10 +480,11 @@ MVN_HD void fx_st_prologue(const StridedParams& P, long base, cfloat* tws, FxStr
 // forward stages) and leaves the next tile's rows to the middle phase, when those registers are
 // free again: both sets ahead of time at once do not fit 128 registers.
 template <int N, int MODE>
-MVN_HD void fx_st_first(const StridedParams& P, long base, long next_base, bool has_next,
+MVN_HD void fx_st_first(const StridedParams& P, long block, long base, long next_base, bool has_next,
                         cfloat* buf, const cfloat* tws, FxStridedRegs<N>& r, int tid) {
   typedef FxStridedCfg<N> C;
-  if (MODE == MVN_ST_FWD_MUL_INV) fx_st_fetch_last<N>(P.spec, P, base, r.g, tid);
+  if (MODE == MVN_ST_FWD_MUL_INV)
+    fx_st_fetch_last_at<N>(fx_spec_tile<N>(P, block, base), fx_spec_estride<N>(P), r.g, tid);
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * C::NT;
@@ -607,7 +622,7 @@ MVN_HD void fx_strided_body(const StridedParams& P, long first, long total, long
       FxStagesQ<N, NT, +1, false, NS - 2, 1, Ctx>::run(buf, tws, ctx);
       MVN_PHASE(ctx, (fx_st_stage0_store<N>(P, base, buf, tws, tid)));
     } else {
-      MVN_PHASE(ctx, (fx_st_first<N, MODE>(P, base, next_base, has_next, buf, tws, r, tid)));
+      MVN_PHASE(ctx, (fx_st_first<N, MODE>(P, block, base, next_base, has_next, buf, tws, r, tid)));
       FxStagesQ<N, NT, -1, true, 1, NS - 2, Ctx>::run(buf, tws, ctx);
       if (MODE == MVN_ST_FWD) {
         MVN_PHASE(ctx, (fx_st_last_store<N>(P, base, buf, tid)));
@@ -670,12 +685,19 @@ MVN_HD void fx_fu_fetch(const cfloat* from, const StridedParams& P, long base, q
 // row order the forward transform produces, i.e. row for row what the LDS holds after it) are
 // requested together; the rows go to the LDS, the operands stay in registers until the multiply
 template <int N>
-MVN_HD void fx_fu_top(const StridedParams& P, long base, cfloat* buf, cfloat* tws,
+MVN_HD void fx_fu_top(const StridedParams& P, long block, long base, cfloat* buf, cfloat* tws,
                       FxFusedRegs<N>& r, int tid) {
   typedef FxFusedCfg<N> C;
   qfloat v[C::U];
   fx_fu_fetch<N>(P.src ? P.src : P.data, P, base, v, tid);
-  fx_fu_fetch<N>(P.spec, P, base, r.g, tid);
+  {  // the tile's PSF operands: same rows and chunks, from the spectrum's own layout
+    const int q = tid % C::CH, jr = tid / C::CH;
+    const long es = fx_spec_estride<N>(P);
+    const cfloat* src = fx_spec_tile<N>(P, block, base) + (long)jr * es + 2 * q;
+    const long rstep = (long)C::RPT * es;
+#pragma unroll
+    for (int u = 0; u < C::U; ++u) r.g[u] = *reinterpret_cast<const qfloat*>(src + u * rstep);
+  }
   fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(N), tid);
   const int q = tid % C::CH, jr = tid / C::CH;
 #pragma unroll
@@ -715,7 +737,7 @@ MVN_HD void fx_fused_lds_body(const StridedParams& P, long block, cfloat* lds, C
   cfloat* buf = lds;
   cfloat* tws = lds + N * TP;
   const long base = fx_st_base<N>(P, block);
-  MVN_PHASE(ctx, (fx_fu_top<N>(P, base, buf, tws, r, tid)));
+  MVN_PHASE(ctx, (fx_fu_top<N>(P, block, base, buf, tws, r, tid)));
   fx_dif<N, T, TP, false, NT, -1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_fu_mul<N>(buf, r, tid)));
   fx_dit<N, T, TP, false, NT, +1>(buf, tws, ctx);

@@ -488,7 +488,10 @@ struct StridedParams {
   AxisPlan ax;
   cfloat* data;        // destination (and source, unless `src` is set)
   const cfloat* src;   // optional separate source with the same addressing (out-of-place pass)
-  const cfloat* spec;  // FWD_MUL_INV: pre-scaled PSF spectrum, same addressing as data
+  const cfloat* spec;  // FWD_MUL_INV: pre-scaled PSF spectrum, same addressing as data ...
+  int spec_tiled;      // ... or (fixed kernels only) tile-contiguous: [tile][row][T columns], so that a
+                       // tile's operands are ONE contiguous stream of n * T * 8 bytes instead of n row
+                       // segments n-1 pages apart
   long ostride;        // between outer slabs
   long estride;        // between elements of a line
   long cstride;        // between neighbouring lines of a tile

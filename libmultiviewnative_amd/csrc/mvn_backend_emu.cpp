@@ -179,20 +179,28 @@ static void emu_wave_rows_mode(const RowsParams& p) {
 }
 
 // fixed-length kernels: every phase is run for all thread ids in turn (real thread mapping)
+// "grid" of a fixed last-axis launch: one workgroup per tile, or for the walking configurations
+// about a third as many, so that the tile loop is exercised
+template <int H>
+static long emu_rows_grid(long ntiles) {
+  return FxRowsCfg<H>::WALK && ntiles > 2 ? (ntiles + 2) / 3 : ntiles;
+}
+
 template <int H>
 static void emu_rows_fused(const RowsParams& p, long ntiles) {
   typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+  const long grid = emu_rows_grid<H>(ntiles);
 #pragma omp parallel
   {
     std::vector<char> lds(sizeof(cfloat) * FxRowsCfg<H>::lds_cfloats + 64);
     std::unique_ptr<Ctx> ctx(new Ctx());
 #pragma omp for schedule(static)
-    for (long t = 0; t < ntiles; ++t) {
+    for (long t = 0; t < grid; ++t) {
       cfloat* l = (cfloat*)lds.data();
       switch (p.epi.mode) {
-        case MVN_EPI_DIVIDE: fx_rows_c2r_r2c_body<H, MVN_EPI_DIVIDE>(p, t, l, *ctx); break;
-        case MVN_EPI_UPDATE: fx_rows_c2r_r2c_body<H, MVN_EPI_UPDATE>(p, t, l, *ctx); break;
-        default: fx_rows_c2r_r2c_body<H, MVN_EPI_STORE>(p, t, l, *ctx); break;
+        case MVN_EPI_DIVIDE: fx_rows_run<H, 2, MVN_EPI_DIVIDE>(p, t, grid, l, *ctx); break;
+        case MVN_EPI_UPDATE: fx_rows_run<H, 2, MVN_EPI_UPDATE>(p, t, grid, l, *ctx); break;
+        default: fx_rows_run<H, 2, MVN_EPI_STORE>(p, t, grid, l, *ctx); break;
       }
     }
   }
@@ -223,21 +231,22 @@ void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int, size_t lds_bytes
 template <int H>
 static void emu_rows_fixed(const RowsParams& p, long ntiles, bool r2c) {
   typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+  const long grid = emu_rows_grid<H>(ntiles);
 #pragma omp parallel
   {
     std::vector<char> lds(sizeof(cfloat) * FxRowsCfg<H>::lds_cfloats + 64);
     std::unique_ptr<Ctx> ctx(new Ctx());
 #pragma omp for schedule(static)
-    for (long t = 0; t < ntiles; ++t) {
+    for (long t = 0; t < grid; ++t) {
+      cfloat* l = (cfloat*)lds.data();
       if (r2c)
-        fx_rows_r2c_body<H>(p, t, (cfloat*)lds.data(), *ctx);
+        fx_rows_run<H, 0, MVN_EPI_STORE>(p, t, grid, l, *ctx);
       else {
-        cfloat* l = (cfloat*)lds.data();
         switch (p.epi.mode) {
-          case MVN_EPI_DIVIDE: fx_rows_c2r_body<H, MVN_EPI_DIVIDE>(p, t, l, *ctx); break;
-          case MVN_EPI_UPDATE: fx_rows_c2r_body<H, MVN_EPI_UPDATE>(p, t, l, *ctx); break;
-          case MVN_EPI_DELTA: fx_rows_c2r_body<H, MVN_EPI_DELTA>(p, t, l, *ctx); break;
-          default: fx_rows_c2r_body<H, MVN_EPI_STORE>(p, t, l, *ctx); break;
+          case MVN_EPI_DIVIDE: fx_rows_run<H, 1, MVN_EPI_DIVIDE>(p, t, grid, l, *ctx); break;
+          case MVN_EPI_UPDATE: fx_rows_run<H, 1, MVN_EPI_UPDATE>(p, t, grid, l, *ctx); break;
+          case MVN_EPI_DELTA: fx_rows_run<H, 1, MVN_EPI_DELTA>(p, t, grid, l, *ctx); break;
+          default: fx_rows_run<H, 1, MVN_EPI_STORE>(p, t, grid, l, *ctx); break;
         }
       }
     }

@@ -766,9 +766,11 @@ struct FxSplitCfg {
   static constexpr int NWL = (W / RL) * CH;  // last-stage work items per window
   static constexpr int ITL = (NWL + NT - 1) / NT;
   static constexpr int TW1 = 0;  // the whole stage-ordered table sits behind the window
-  // measured: the forward form (row-permuted accesses, a little more register pressure) wins at
-  // 1280 (0.263 -> 0.246 ms) and loses at 1920 (2.77 -> 2.95 ms, 172 bytes of scratch)
-  static constexpr bool FWD_DEFAULT = N <= 1280;
+  // the forward form (row-permuted accesses, a little more register pressure): round 1 measured a
+  // win at 1280 (0.263 -> 0.246 ms) and a loss at 1920 (2.77 -> 2.95 ms, 172 bytes of scratch);
+  // built without SLP vectorisation (packed f32 math costs registers and issue slots on gfx950)
+  // the 1920 kernel keeps 28 bytes of scratch and wins too: 2.91 -> 2.37 ms on 320 x 1920 x 1920
+  static constexpr bool FWD_DEFAULT = true;
   static constexpr int lds_cfloats = W * TP + (fx_twsize(N) - TW1);
   static_assert(!USE || (fx_radix(N, 0) == 8 && NS >= 3 && N % 128 == 0 && W % RL == 0), "split plan");
   static_assert(!USE || (NT % 64 == 0 && NT * IT0 == NT1), "split workgroup size");
@@ -1006,7 +1008,20 @@ struct FxRowsCfg {
 #ifndef MVN_FX_ROWS_T
 #define MVN_FX_ROWS_T 16
 #endif
-  static constexpr int T = H > 512 ? 8 : ((fx_pow2(H) && H >= 128) ? MVN_FX_ROWS_T : 16);
+  // Long rows (H > 512): a 16-row tile would not fit, and the 8-row tile (86 KB with its tables at
+  // H = 960) leaves ONE workgroup per CU, whose load, transform and store phases then never overlap
+  // with anything (measured at 320 x 1920 x 1920: the fused passes at 3.0 / 3.7 TB/s).  These lengths
+  // use 2-row tiles instead: several small workgroups per CU (40 KB each at H = 960), which WALK over
+  // the tiles of the launch so that the 16 KB of tables are built once per workgroup, not per tile.
+#ifndef MVN_FX_ROWS_SMALL_MIN
+#define MVN_FX_ROWS_SMALL_MIN 513
+#endif
+  static constexpr bool SMALL = H >= MVN_FX_ROWS_SMALL_MIN;
+  static constexpr bool WALK = SMALL;
+#ifndef MVN_FX_ROWS_SMALL_T
+#define MVN_FX_ROWS_SMALL_T 2
+#endif
+  static constexpr int T = SMALL ? MVN_FX_ROWS_SMALL_T : (H > 512 ? 8 : ((fx_pow2(H) && H >= 128) ? MVN_FX_ROWS_T : 16));
   static constexpr int TP = T + 1;
   static constexpr int QR = H / 2;  // 16-byte chunks per spectral row (2 complex bins each)
   static constexpr int R0 = fx_radix(H, 0);
@@ -1016,15 +1031,20 @@ struct FxRowsCfg {
 #ifndef MVN_FX_ROWS_NT_CAP
 #define MVN_FX_ROWS_NT_CAP 1024
 #endif
-  static constexpr int NT = fx_pick_nt(MVN_FX_ROWS_NT_CAP, H * T / 8 >= 64 ? H * T / 8 : 64, T * QR, M0 * T, H / 2 * T);
-  static constexpr int U = T * QR / (NT > 0 ? NT : 1);   // 16-byte spectral loads/stores per thread
-  static constexpr int IT0 = (M0 * T) / (NT > 0 ? NT : 1);  // stage-0 butterflies per thread
+  // (small tiles: one stage-0 butterfly per thread, rounded up to whole waves; the last threads
+  // of a sweep then idle -- every per-thread loop below is guarded where the counts do not divide)
+  static constexpr int NT = SMALL ? ((M0 * T + 63) / 64) * 64
+                                  : fx_pick_nt(MVN_FX_ROWS_NT_CAP, H * T / 8 >= 64 ? H * T / 8 : 64, T * QR, M0 * T, H / 2 * T);
+  static constexpr int NTD = NT > 0 ? NT : 1;
+  static constexpr int U = (T * QR + NTD - 1) / NTD;   // 16-byte spectral loads/stores per thread
+  static constexpr int IT0 = (M0 * T + NTD - 1) / NTD;  // stage-0 butterflies per thread
+  static constexpr bool EXACT = (T * QR) % NTD == 0 && (M0 * T) % NTD == 0 && (H / 2 * T) % NTD == 0;
   static constexpr int ROWS = fx_rows_alloc(H, PAD);
   static constexpr int TILE = (ROWS * TP + 1) & ~1;  // keeps the tables behind it 16-byte aligned
   // tile | stage twiddles | d2-th roots (H/2+1, padded to even) | pair table (H/2 entries of 2 ints)
   static constexpr int TWR = (H / 2 + 2) & ~1;
   static constexpr int lds_cfloats = TILE + fx_twsize(H) + TWR + H / 2;
-  static constexpr int ITP = (H / 2 * T) / (NT > 0 ? NT : 1);  // bin pairs per thread in the real<->complex step
+  static constexpr int ITP = (H / 2 * T + NTD - 1) / NTD;  // bin pairs per thread in the real<->complex step
   static_assert(fx_smooth(H) && H % 2 == 0 && H >= 32 && H <= 1024, "unsupported fixed length");
   static_assert(NT >= 64 && R0 == 8, "stage 0: whole radix-8 butterflies per thread");
   static_assert(sizeof(cfloat) * lds_cfloats <= 160 * 1024, "tile does not fit the LDS");
@@ -1068,6 +1088,16 @@ MVN_HD void fx_load_tw_row(const cfloat* row, cfloat* tw) {
   }
 }
 
+// the tables of a last-axis workgroup: stage twiddles, d2-th roots, pair offsets (built per tile by
+// the one-tile kernels, once per workgroup by the walking ones)
+template <int H>
+MVN_HD void fx_rows_tables(const RowsParams& P, cfloat* tws, cfloat* twr, int tid) {
+  typedef FxRowsCfg<H> C;
+  fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(H), tid);
+  fx_copy_table<C::NT>(twr, P.twr, H / 2 + 1, tid);
+  fx_build_pair_table<H>(reinterpret_cast<FxPair*>(twr + C::TWR), tid);
+}
+
 // r2c phase A: global load -> first forward stage in registers -> LDS
 template <int H>
 MVN_HD void fx_r2c_load_stage0(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, cfloat* twr,
@@ -1078,20 +1108,21 @@ MVN_HD void fx_r2c_load_stage0(const RowsParams& P, long r0, cfloat* buf, cfloat
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * NT;
+    if (!C::EXACT && w >= M * C::T) break;
     const int j2 = w % M, rho = w / M;
     const cfloat* src = reinterpret_cast<const cfloat*>(P.in_real + (r0 + rho) * P.RP) + j2;
 #pragma unroll
     for (int j = 0; j < R; ++j) a[it][j] = src[j * M];
   }
-  fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(H), tid);
-  fx_copy_table<NT>(twr, P.twr, H / 2 + 1, tid);
-  fx_build_pair_table<H>(reinterpret_cast<FxPair*>(twr + C::TWR), tid);
+  if (!C::WALK) fx_rows_tables<H>(P, tws, twr, tid);
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * NT;
+    if (!C::EXACT && w >= M * C::T) break;
     const int j2 = w % M, rho = w / M;
     cfloat tw[fx_rs(R)];
-    fx_load_tw_row<R>(P.ax.tws + j2 * fx_rs(R), tw);  // stage 0 opens the table; the LDS copy is not ready yet
+    // stage 0 opens the table; a one-tile workgroup's LDS copy is not ready yet
+    fx_load_tw_row<R>((C::WALK ? (const cfloat*)tws : P.ax.tws) + j2 * fx_rs(R), tw);
     dftR<R, -1>(a[it]);
 #pragma unroll
     for (int k = 1; k < R; ++k) a[it][k] = cmul(a[it][k], tw[k]);
@@ -1111,6 +1142,7 @@ MVN_HD void fx_r2c_post(const RowsParams& P, long r0, cfloat* buf, const cfloat*
 #pragma unroll
   for (int it = 0; it < C::ITP; ++it) {
     const int i = tid + it * NT;
+    if (!C::EXACT && i >= H / 2 * T) break;
     const int k = i / T, rho = i % T;
     const FxPair t = tab[k];
     cfloat* pa = buf + t.a + rho;
@@ -1138,6 +1170,7 @@ MVN_HD void fx_r2c_store(const RowsParams& P, long r0, const cfloat* buf, int ti
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
+    if (!C::EXACT && e >= C::T * C::QR) break;
     const int rho = e / C::QR, kk = e % C::QR;
     // spectral rows are kept in position (digit-reversed) order: bin k sits at column inv(k)
     const cfloat a = buf[fx_row<C::PAD>(2 * kk) * TP + rho];
@@ -1178,6 +1211,7 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
+    if (!C::EXACT && e >= C::T * C::QR) break;
     const int rho = e / C::QR, kk = e % C::QR;
     r.v[u] = reinterpret_cast<const qfloat*>(P.in_cplx + (r0 + rho) * P.C)[kk];
   }
@@ -1187,6 +1221,7 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
 #pragma unroll
     for (int it = 0; it < C::IT0; ++it) {
       const int w = tid + it * NT;
+      if (!C::EXACT && w >= C::M0 * C::T) break;
       const cfloat* src = reinterpret_cast<const cfloat*>(pa + (r0 + w / C::M0) * P.RP) + (w % C::M0);
 #pragma unroll
       for (int jo = 0; jo < C::R0; ++jo) r.ea[it][jo] = src[jo * C::M0];
@@ -1196,18 +1231,18 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
 #pragma unroll
     for (int it = 0; it < C::IT0; ++it) {
       const int w = tid + it * NT;
+      if (!C::EXACT && w >= C::M0 * C::T) break;
       const cfloat* src =
           reinterpret_cast<const cfloat*>(P.epi.weights + (r0 + w / C::M0) * P.RP) + (w % C::M0);
 #pragma unroll
       for (int jo = 0; jo < C::R0; ++jo) r.eb[it][jo] = src[jo * C::M0];
     }
   }
-  fx_copy_table<NT>(tws, P.ax.tws, fx_twsize(H), tid);
-  fx_copy_table<NT>(twr, P.twr, H / 2 + 1, tid);
-  fx_build_pair_table<H>(reinterpret_cast<FxPair*>(twr + C::TWR), tid);
+  if (!C::WALK) fx_rows_tables<H>(P, tws, twr, tid);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
+    if (!C::EXACT && e >= C::T * C::QR) break;
     const int rho = e / C::QR, kk = e % C::QR;
     buf[fx_row<C::PAD>(2 * kk) * TP + rho] = cmake(r.v[u].x, r.v[u].y);
     buf[fx_row<C::PAD>(2 * kk + 1) * TP + rho] = cmake(r.v[u].z, r.v[u].w);
@@ -1224,6 +1259,7 @@ MVN_HD void fx_c2r_pre(const RowsParams& P, long r0, cfloat* buf, const cfloat* 
 #pragma unroll
   for (int it = 0; it < C::ITP; ++it) {
     const int i = tid + it * NT;
+    if (!C::EXACT && i >= H / 2 * T) break;
     const int k = i / T, rho = i % T;
     const FxPair t = tab[k];
     cfloat* pa = buf + t.a + rho;
@@ -1256,6 +1292,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * NT;
+    if (!C::EXACT && w >= M * C::T) break;
     const int j2 = w % M, rho = w / M;
     cfloat* p = buf + fx_row<C::PAD>(j2) * TP + rho;
     cfloat a[R];
@@ -1323,4 +1360,32 @@ MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
   fx_dit<H, T, TP, C::PAD, NT, +1, 1>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, false, EPI>(P, r0, buf, tws, r, tid)));
+}
+
+// One workgroup of a last-axis launch: its single tile, or (FxRowsCfg<H>::WALK) the tables once
+// and then tiles block, block + nblocks, ...  KIND 0: r2c, 1: c2r, 2: c2r + pointwise + r2c.
+template <int H, int KIND, int EPI, typename Ctx>
+MVN_HD void fx_rows_tile(const RowsParams& P, long tile, cfloat* lds, Ctx& ctx) {
+  if constexpr (KIND == 0)
+    fx_rows_r2c_body<H>(P, tile, lds, ctx);
+  else if constexpr (KIND == 1)
+    fx_rows_c2r_body<H, EPI>(P, tile, lds, ctx);
+  else
+    fx_rows_c2r_r2c_body<H, EPI>(P, tile, lds, ctx);
+}
+
+template <int H, int KIND, int EPI, typename Ctx>
+MVN_HD void fx_rows_run(const RowsParams& P, long block, long nblocks, cfloat* lds, Ctx& ctx) {
+  typedef FxRowsCfg<H> C;
+  if constexpr (C::WALK) {
+    constexpr int NT_ = C::NT;
+    (void)NT_;
+    cfloat* tws = lds + C::TILE;
+    cfloat* twr = tws + fx_twsize(H);
+    MVN_PHASE(ctx, (fx_rows_tables<H>(P, tws, twr, tid)));
+    const long ntiles = P.rows / C::T;
+    for (long tile = block; tile < ntiles; tile += nblocks) fx_rows_tile<H, KIND, EPI>(P, tile, lds, ctx);
+  } else {
+    fx_rows_tile<H, KIND, EPI>(P, block, lds, ctx);
+  }
 }

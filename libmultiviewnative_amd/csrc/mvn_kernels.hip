@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_r2c(const RowsParams
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_r2c_body<H>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_run<H, 0, MVN_EPI_STORE>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
 template <int H, int EPI>
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_c2r_body<H, EPI>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_run<H, 1, EPI>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
 // (The divide form needs 93 VGPRs, just above the 84 that would let three 512-thread workgroups
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsPa
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_c2r_r2c_body<H, EPI>(p, (long)MVN_PROBE_TILE(blockIdx.x), (cfloat*)mvn_smem, ctx);
+  fx_rows_run<H, 2, EPI>(p, (long)MVN_PROBE_TILE(blockIdx.x), (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
 // last-axis passes for d2 = 512 in which a row never leaves its half-wave (mvn_wave_rows.hpp): no
@@ -392,6 +392,12 @@ static void launch_pass(K kernel, const P& p, long nblocks, int nthreads, size_t
   HIP_CHECK(hipGetLastError());
 }
 
+// fixed last-axis kernels: one workgroup per tile, or (long rows, FxRowsCfg<H>::WALK) as many
+// workgroups as the device holds at once, each walking over the tiles of the launch
+template <bool WALK, typename K>
+static void launch_rows_fixed(K kernel, const RowsParams& p, long nblocks, int nthreads, size_t lds_bytes,
+                              stream_t s);
+
 // Fixed strided kernels walk over several tiles per workgroup (the next tile's loads overlap the
 // current tile's LDS stages): the grid is what the device holds at once, not one block per tile.
 // MVN_PERSIST=0 launches one workgroup per tile (same kernel, no overlap across tiles);
@@ -489,6 +495,18 @@ static void launch_wave_rows(K kernel, const RowsParams& p, stream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+template <bool WALK, typename K>
+static void launch_rows_fixed(K kernel, const RowsParams& p, long nblocks, int nthreads, size_t lds_bytes,
+                              stream_t s) {
+  if (WALK) {
+    ensure_lds(kernel, lds_bytes);
+    const long resident = (long)resident_per_cu(reinterpret_cast<const void*>(kernel), nthreads, lds_bytes) *
+                          device_cu_count();
+    if (nblocks > resident) nblocks = resident;
+  }
+  launch_pass(kernel, p, nblocks, nthreads, lds_bytes, s);
+}
+
 #define MVN_DISPATCH_T(T_, KERNEL_EXPR)                                        \
   switch (T_) {                                                                \
     case 16: { constexpr int TT = 16; launch_pass(KERNEL_EXPR, p, nblocks, nthreads, lds_bytes, s); } break; \
@@ -511,7 +529,7 @@ void launch_rows_r2c(const RowsParams& p, bool even, long nblocks, int nthreads,
     check_aligned16(p.out_cplx, "output");
     if (wave_rows_enabled(p, 1)) return launch_wave_rows(kw_rows<MVN_WR_R2C, MVN_EPI_STORE>, p, s);
     switch (p.h) {
-#define X(H) case H: launch_pass(kx_rows_r2c<H>, p, nblocks, nthreads, lds_bytes, s); return;
+#define X(H) case H: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_r2c<H>, p, nblocks, nthreads, lds_bytes, s); return;
       MVN_FIXED_ROWS_LENGTHS(X)
 #undef X
       default: throw std::invalid_argument("mvn: no fixed rows kernel for this length");
@@ -542,10 +560,10 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
 #define X(H)                                                                                  \
   case H:                                                                                     \
     switch (p.epi.mode) {                                                                     \
-      case MVN_EPI_DIVIDE: launch_pass(kx_rows_c2r<H, MVN_EPI_DIVIDE>, p, nblocks, nthreads, lds_bytes, s); break; \
-      case MVN_EPI_UPDATE: launch_pass(kx_rows_c2r<H, MVN_EPI_UPDATE>, p, nblocks, nthreads, lds_bytes, s); break; \
-      case MVN_EPI_DELTA: launch_pass(kx_rows_c2r<H, MVN_EPI_DELTA>, p, nblocks, nthreads, lds_bytes, s); break;   \
-      default: launch_pass(kx_rows_c2r<H, MVN_EPI_STORE>, p, nblocks, nthreads, lds_bytes, s); break;             \
+      case MVN_EPI_DIVIDE: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_c2r<H, MVN_EPI_DIVIDE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      case MVN_EPI_UPDATE: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_c2r<H, MVN_EPI_UPDATE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      case MVN_EPI_DELTA: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_c2r<H, MVN_EPI_DELTA>, p, nblocks, nthreads, lds_bytes, s); break;   \
+      default: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_c2r<H, MVN_EPI_STORE>, p, nblocks, nthreads, lds_bytes, s); break;             \
     }                                                                                         \
     return;
       MVN_FIXED_ROWS_LENGTHS(X)
@@ -580,9 +598,9 @@ void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t
 #define X(H)                                                                                  \
   case H:                                                                                     \
     switch (p.epi.mode) {                                                                     \
-      case MVN_EPI_DIVIDE: launch_pass(kx_rows_c2r_r2c<H, MVN_EPI_DIVIDE>, p, nblocks, nthreads, lds_bytes, s); break; \
-      case MVN_EPI_UPDATE: launch_pass(kx_rows_c2r_r2c<H, MVN_EPI_UPDATE>, p, nblocks, nthreads, lds_bytes, s); break; \
-      default: launch_pass(kx_rows_c2r_r2c<H, MVN_EPI_STORE>, p, nblocks, nthreads, lds_bytes, s); break;             \
+      case MVN_EPI_DIVIDE: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_c2r_r2c<H, MVN_EPI_DIVIDE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      case MVN_EPI_UPDATE: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_c2r_r2c<H, MVN_EPI_UPDATE>, p, nblocks, nthreads, lds_bytes, s); break; \
+      default: launch_rows_fixed<FxRowsCfg<H>::WALK>(kx_rows_c2r_r2c<H, MVN_EPI_STORE>, p, nblocks, nthreads, lds_bytes, s); break;             \
     }                                                                                         \
     return;
     MVN_FIXED_ROWS_LENGTHS(X)

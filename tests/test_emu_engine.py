@@ -670,3 +670,34 @@ def test_wave_row_kernels_d2_512(emu, monkeypatch, mask):
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
     ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 1920), (3, 4, 2048), (2, 5, 1280), (2, 4, 1536)])
+def test_long_rows_small_tile_walking_kernels(emu, shape):
+    # rows longer than 1024 floats (H > 512): 2-row tiles, workgroups that walk over the tiles with
+    # their tables built once, per-thread loops guarded where the counts do not divide (H = 960:
+    # 240 stage-0 butterflies on 256 threads)
+    assert emu.plan_describe(shape)["fx_rows"] == 1
+    x = np.random.default_rng(2).standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = emu.rfft3(x)
+    assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max()
+    back = emu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 2e-5
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (1, 3, 9), seed=4)
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 2)
+        got = emu.gpu_deconvolve(psi0, h)
+        ref = orc.cpu_deconvolve(psi0, h, 4)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    e = emu.engine(shape, 2)
+    for v in range(2):
+        e.set_view(v, views[v], w[v], k1[v], k2[v])
+    e.set_psi(psi0)
+    e.compute_delta(0.006, 1e-4)
+    e.apply_delta()
+    got = e.get_psi()
+    e.close()
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()

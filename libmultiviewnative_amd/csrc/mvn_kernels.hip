@@ -462,11 +462,11 @@ static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads
 
 // wave-row kernels (d2 = 512): workgroups sweep over the row pairs, the grid is what the device
 // holds at once.  MVN_WAVE_ROWS_MASK selects the passes that use them (1 plain r2c, 2 plain c2r,
-// 4 fused divide, 8 fused update / store); MVN_NO_WAVE_ROWS=1 = mask 0.  Default 4: measured at
-// 512^3 on MI355X (bench.py, same box) the fused divide gains 4 % (0.347 -> 0.333 ms), the fused
-// update is even and the plain r2c / c2r passes, which the tiled kernels already run at the
-// streaming ceiling, lose 5-10 %; from L2-resident data (timing probe) the wave-row forms are
-// 12-14 % faster than the tiled ones, i.e. the difference is hidden behind HBM.
+// 4 fused divide, 8 fused update / store); MVN_NO_WAVE_ROWS=1 = mask 0.  Default 12: measured at
+// 512^3 on MI355X (tools/ab_env.sh, same box) the fused divide gains 12 % over the tiled kernel
+// (0.376 -> 0.330 ms) and, with the twiddle tables transposed in the LDS, the fused update 2 %
+// (0.485 -> 0.475 ms); the plain r2c / c2r passes, which the tiled kernels already run at the
+// streaming ceiling, lose 3-8 % and stay tiled.
 static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
   static const bool off = [] {
     const char* e = std::getenv("MVN_NO_WAVE_ROWS");
@@ -474,7 +474,7 @@ static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
   }();
   static const int mask = [] {
     const char* e = std::getenv("MVN_WAVE_ROWS_MASK");
-    return e && *e ? std::atoi(e) : 4;
+    return e && *e ? std::atoi(e) : 12;
   }();
   return !off && (mask & kind_bit) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
 }

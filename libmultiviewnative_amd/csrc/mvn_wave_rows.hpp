@@ -37,7 +37,8 @@ struct WrCfg {
   static constexpr int NT = 64 * WAVES;
   static constexpr int RB = 288;       // cfloats per LDS row buffer: 256 + 4 spare per 32 positions
   static constexpr int TW = fx_twsize(H);  // stage-ordered twiddle table (stage 0: 32 rows, stage 1: 4 rows)
-  static constexpr int lds_cfloats = TW + WAVES * 2 * RB;
+  static constexpr int PWT = 4 * LPR;   // the lanes' pair twiddles, [j][lane] (update forms, see wr_pw)
+  static constexpr int lds_cfloats = TW + WAVES * 2 * RB + PWT;
   static_assert(fx_radix(H, 0) == 8 && fx_radix(H, 1) == 8 && fx_radix(H, 2) == 4 && fx_nstages(H) == 3,
                 "wave-row kernels are written for 256 = 8 * 8 * 4");
 };
@@ -85,8 +86,33 @@ MVN_HD cfloat wr_root(const cfloat* twr, int k) {
   return cmake(-w.x, w.y);  // exp(-2 pi i (H - k') / 2H) = -conj(exp(-2 pi i k' / 2H))
 }
 
+// The stage twiddle tables in the LDS, TRANSPOSED: entry k of butterfly row j sits at [k][j], so the
+// lanes of a half-wave (which own rows j = t, or j = t & 3 in the middle stages) read neighbouring
+// 8-byte words.  In the row-major order of the tiled kernels lane t's row starts 64 bytes behind
+// lane t - 1's and 16 lanes share two bank groups: measured (SQ_LDS_BANK_CONFLICT) 58 % of the
+// pass's LDS cycles were conflict cycles, nearly all of them these reads.
+MVN_HD void wr_copy_tables(cfloat* dst, const cfloat* src, int tid) {
+  constexpr int S1 = fx_twoff(WrCfg::H, 1);  // 32 rows of 8 (stage 0), then 4 rows of 8 (stage 1)
+  static_assert(S1 == 256 && WrCfg::TW == 288, "twiddle table of 256 = 8 * 8 * 4");
+  for (int i = tid; i < WrCfg::TW; i += WrCfg::NT) {
+    const int d = i < S1 ? (i & 7) * 32 + (i >> 3) : S1 + ((i - S1) & 7) * 4 + ((i - S1) >> 3);
+    dst[d] = src[i];
+  }
+}
+// twiddles of butterfly row j of stage 0 / stage 1 (entry 0 is 1 and never read)
+MVN_HD void wr_tw0(const cfloat* tws, int j, cfloat* tw) {
+#pragma unroll
+  for (int k = 1; k < 8; ++k) tw[k] = tws[k * 32 + j];
+}
+MVN_HD void wr_tw1(const cfloat* tws, int j, cfloat* tw) {
+#pragma unroll
+  for (int k = 1; k < 8; ++k) tw[k] = tws[fx_twoff(WrCfg::H, 1) + k * 4 + j];
+}
+
+MVN_HD cfloat* wr_pwt(cfloat* rows) { return rows + WrCfg::WAVES * 2 * WrCfg::RB; }
+
 // once per kernel: the lane's pair twiddles
-MVN_HD void wr_setup(const RowsParams& P, WrRegs& r, int tid) {
+MVN_HD void wr_setup(const RowsParams& P, WrRegs& r, cfloat* rows, int tid) {
   const int t = tid & 31;
   if (t == 0) {
     r.pw[0] = wr_root(P.twr, 64);  // group 0: bins 64 <-> 192
@@ -100,6 +126,23 @@ MVN_HD void wr_setup(const RowsParams& P, WrRegs& r, int tid) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) r.pw[j] = wr_root(P.twr, k0 + 64 * j);
   }
+  if (tid < WrCfg::LPR) {  // the same for every half-wave: one copy per workgroup (wr_pw)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr_pwt(rows)[j * WrCfg::LPR + t] = r.pw[j];
+  }
+}
+
+// The update forms sit at the 128-register limit of four waves per SIMD: they re-read the lane's four
+// pair twiddles from a 1 KB LDS table in phases A and E instead of keeping them in 8 registers.
+template <int EPI>
+constexpr bool wr_pw_in_lds() {
+  return EPI == MVN_EPI_UPDATE || EPI == MVN_EPI_DELTA;
+}
+template <int EPI>
+MVN_HD void wr_pw(const WrRegs& r, const cfloat* rows, int t, cfloat* pw) {
+  const cfloat* tab = rows + WrCfg::WAVES * 2 * WrCfg::RB;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pw[j] = wr_pw_in_lds<EPI>() ? tab[j * WrCfg::LPR + t] : r.pw[j];
 }
 
 // half-complex -> complex step on one pair: X[k], X[H-k] -> Z[k], Z[H-k]
@@ -132,6 +175,11 @@ MVN_HD void wr_post_pair(cfloat& zk, cfloat& zm, cfloat w) {
 MVN_HD long wr_row(long block, long nblocks, long it, int tid) {
   const long pair = (it * nblocks + block) * WrCfg::WAVES + (tid >> 6);
   return 2 * (long)MVN_PROBE_TILE(pair) + ((tid >> 5) & 1);
+}
+
+// component-wise select (a select of the aggregates goes through a stack slot)
+MVN_HD qfloat wr_pick(int c, qfloat a, qfloat b) {
+  return qmake(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 
 MVN_HD cfloat* wr_buf(cfloat* rows, int tid) { return rows + (tid >> 5) * WrCfg::RB; }
@@ -167,27 +215,42 @@ MVN_HD void wr_phase_a(const RowsParams& P, long row, long next_row, cfloat* row
   const qfloat a0 = r.nx[0], a1 = r.nx[1], b0 = r.nx[2], b1 = r.nx[3];
   cfloat za[4] = {cmake(a0.x, a0.y), cmake(a0.z, a0.w), cmake(a1.x, a1.y), cmake(a1.z, a1.w)};
   cfloat zb[4] = {cmake(b0.x, b0.y), cmake(b0.z, b0.w), cmake(b1.x, b1.y), cmake(b1.z, b1.w)};
+  cfloat pw[4];
+  wr_pw<EPI>(r, rows, t, pw);
   if (t == 0) {
     // imaginary parts of the DC and Nyquist bins are ignored, as FFTW's c2r does
     const float xh = P.in_nyq[row].x;
     za[0] = cmake(za[0].x + xh, za[0].x - xh);
-    wr_pre_pair(za[1], za[3], r.pw[0]);
+    wr_pre_pair(za[1], za[3], pw[0]);
     za[2] = cmake(2.f * za[2].x, -2.f * za[2].y);  // bin H/2 pairs with itself: Z = 2 conj(X)
-    wr_pre_pair(zb[0], zb[3], r.pw[1]);
-    wr_pre_pair(zb[1], zb[2], r.pw[2]);
+    wr_pre_pair(zb[0], zb[3], pw[1]);
+    wr_pre_pair(zb[1], zb[2], pw[2]);
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wr_pre_pair(za[j], zb[3 - j], r.pw[j]);
+    for (int j = 0; j < 4; ++j) wr_pre_pair(za[j], zb[3 - j], pw[j]);
   }
   dftR<4, +1>(za);  // last stage (M = 1): no twiddles
   dftR<4, +1>(zb);
   cfloat* buf = wr_buf(rows, tid);
   qfloat* da = reinterpret_cast<qfloat*>(buf + wr_f(4 * ga));
   qfloat* db = reinterpret_cast<qfloat*>(buf + wr_f(4 * gb));
-  da[0] = qmake(za[0].x, za[0].y, za[1].x, za[1].y);
-  da[1] = qmake(za[2].x, za[2].y, za[3].x, za[3].y);
-  db[0] = qmake(zb[0].x, zb[0].y, zb[1].x, zb[1].y);
-  db[1] = qmake(zb[2].x, zb[2].y, zb[3].x, zb[3].y);
+  // a lane's two 16-byte halves go out in an order that depends on the lane (lanes 4..7 of every
+  // eight start with the upper half): the eight lanes one ds_write_b128 serves together then hit
+  // eight different 16-byte bank groups; both halves in program order are 2-way conflicted.  The
+  // fences keep the selects of one group from overlapping the other group's registers and the
+  // global loads below from being hoisted over both (that spilled).
+  const int hi = (t >> 2) & 1;
+  {
+    const qfloat u = qmake(za[0].x, za[0].y, za[1].x, za[1].y), v = qmake(za[2].x, za[2].y, za[3].x, za[3].y);
+    da[hi] = wr_pick(hi, v, u);
+    da[hi ^ 1] = wr_pick(hi, u, v);
+  }
+  {
+    const qfloat u = qmake(zb[0].x, zb[0].y, zb[1].x, zb[1].y), v = qmake(zb[2].x, zb[2].y, zb[3].x, zb[3].y);
+    db[hi] = wr_pick(hi, v, u);
+    db[hi ^ 1] = wr_pick(hi, u, v);
+  }
+  MVN_SCHED_FENCE();
   if (wr_prefetch<EPI>()) wr_fetch_row(P, next_row, r, tid);
   // the operands of the pointwise step are requested now, one LDS stage ahead of their use (phase
   // C: the lane finishes reals 2 (t + 32 jo), 2 (t + 32 jo) + 1); the row registers are free again
@@ -214,7 +277,7 @@ MVN_HD void wr_phase_mid(long row, long nrows, cfloat* rows, const cfloat* tws, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) a[j] = p[4 * j];
   cfloat tw[8];
-  fx_load_tw_row<8>(tws + fx_twoff(WrCfg::H, 1) + j2 * 8, tw);
+  wr_tw1(tws, j2, tw);
   if (SIGN > 0) {  // inverse: decimation in time, twiddles first
 #pragma unroll
     for (int k = 1; k < 8; ++k) a[k] = cmul(a[k], cconj(tw[k]));
@@ -238,7 +301,7 @@ MVN_HD void wr_phase_c(const RowsParams& P, long row, cfloat* rows, const cfloat
   cfloat* p = wr_buf(rows, tid) + t;  // wr_f(t + 32 j) = t + 36 j
   cfloat a[8];
   cfloat tw[8];
-  fx_load_tw_row<8>(tws + t * 8, tw);
+  wr_tw0(tws, t, tw);
   const long i0 = row * P.RP + 2 * t;  // the lane's reals: i0 + 64 jo, i0 + 64 jo + 1
   if (MODE == MVN_WR_R2C) {
     const float* src = P.in_real + i0;
@@ -269,9 +332,9 @@ MVN_HD void wr_phase_c(const RowsParams& P, long row, cfloat* rows, const cfloat
     // the twiddle row is read again rather than kept across the pointwise step (16 registers
     // next to its operands and the f64 chains of the update); the offset is made opaque so that
     // the two reads are not merged
-    int off = t * 8;
+    int off = t;
     MVN_JIT_ADDRESS(off);
-    fx_load_tw_row<8>(tws + off, tw);
+    wr_tw0(tws, off, tw);
   }
 #pragma unroll
   for (int k = 1; k < 8; ++k) a[k] = cmul(a[k], tw[k]);
@@ -280,6 +343,7 @@ MVN_HD void wr_phase_c(const RowsParams& P, long row, cfloat* rows, const cfloat
 }
 
 // ---- phase E: forward radix-4 stage, complex -> half-complex, spectral row out -------------------
+template <int EPI>
 MVN_HD void wr_phase_e(const RowsParams& P, long row, const cfloat* rows, const WrRegs& r, int tid) {
   if (row >= P.rows) return;
   const int t = tid & 31;
@@ -293,17 +357,19 @@ MVN_HD void wr_phase_e(const RowsParams& P, long row, const cfloat* rows, const 
   cfloat zb[4] = {cmake(b0.x, b0.y), cmake(b0.z, b0.w), cmake(b1.x, b1.y), cmake(b1.z, b1.w)};
   dftR<4, -1>(za);
   dftR<4, -1>(zb);
+  cfloat pw[4];
+  wr_pw<EPI>(r, rows, t, pw);
   if (t == 0) {
     const cfloat z0 = za[0];
     za[0] = cmake(z0.x + z0.y, 0.f);                      // DC
     P.out_nyq[row] = cmake(z0.x - z0.y, 0.f);             // Nyquist, kept in its own plane
-    wr_post_pair(za[1], za[3], r.pw[0]);
+    wr_post_pair(za[1], za[3], pw[0]);
     za[2] = cconj(za[2]);                                 // bin H/2 pairs with itself
-    wr_post_pair(zb[0], zb[3], r.pw[1]);
-    wr_post_pair(zb[1], zb[2], r.pw[2]);
+    wr_post_pair(zb[0], zb[3], pw[1]);
+    wr_post_pair(zb[1], zb[2], pw[2]);
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wr_post_pair(za[j], zb[3 - j], r.pw[j]);
+    for (int j = 0; j < 4; ++j) wr_post_pair(za[j], zb[3 - j], pw[j]);
   }
   qfloat* dst = reinterpret_cast<qfloat*>(P.out_cplx + row * P.C);
   dst[2 * ga] = qmake(za[0].x, za[0].y, za[1].x, za[1].y);
@@ -336,7 +402,7 @@ MVN_HD void wr_rows_body(const RowsParams& P, long block, long nblocks, cfloat* 
   (void)NT_;
   cfloat* tws = lds;
   cfloat* rows = lds + WrCfg::TW;
-  MVN_PHASE(ctx, (fx_copy_table<WrCfg::NT>(tws, P.ax.tws, WrCfg::TW, tid), wr_setup(P, r, tid),
+  MVN_PHASE(ctx, (wr_copy_tables(tws, P.ax.tws, tid), wr_setup(P, r, rows, tid),
                   (MODE != MVN_WR_R2C && wr_prefetch<EPI>()) ? wr_fetch_row(P, wr_row(block, nblocks, 0, tid), r, tid)
                                                              : (void)0));
   const long pairs = (P.rows + 1) / 2;
@@ -351,7 +417,7 @@ MVN_HD void wr_rows_body(const RowsParams& P, long block, long nblocks, cfloat* 
     MVN_WPHASE(ctx, (wr_phase_c<MODE, EPI>(P, wr_row(block, nblocks, it, tid), rows, tws, r, tid)));
     if (MODE != MVN_WR_C2R) {
       MVN_WPHASE(ctx, (wr_phase_mid<-1>(wr_row(block, nblocks, it, tid), P.rows, rows, tws, tid)));
-      MVN_WPHASE(ctx, (wr_phase_e(P, wr_row(block, nblocks, it, tid), rows, r, tid)));
+      MVN_WPHASE(ctx, (wr_phase_e<EPI>(P, wr_row(block, nblocks, it, tid), rows, r, tid)));
     }
   }
 }

@@ -24,7 +24,9 @@
 #include <hip/hip_runtime.h>
 #define MVN_HD __host__ __device__ __forceinline__
 #define MVN_D __device__ __forceinline__
-typedef float2 cfloat;
+// a native two-float vector: complex values live in 64-bit register pairs, which is what the
+// packed f32 instructions of gfx950 operate on (see the complex helpers below)
+typedef float cfloat __attribute__((ext_vector_type(2)));
 #define MVN_SYNC() __syncthreads()
 #else
 #define MVN_HD inline
@@ -78,13 +80,105 @@ MVN_HD cfloat cmake(float x, float y) {
   r.y = y;
   return r;
 }
+// ---------------------------------------------------------------------------------------------
+// complex arithmetic.  gfx950 executes two f32 operations per lane in one packed instruction
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on 64-bit register pairs); every source operand can
+// feed either of its halves to either result half (op_sel / op_sel_hi) and be negated per half
+// (neg_lo / neg_hi).  With those modifiers a complex add, an add of +-i times a value and an add of a
+// conjugate are ONE instruction each and a complex product is two, about half the instruction
+// count of the scalar forms.  hipcc folds whole-vector negations into the modifiers but not the
+// swap-and-negate-one-half patterns (it emits v_mov + v_xor for them), hence the inline forms on
+// the device; the host emulation (and MVN_NO_PACKED builds, for A/B runs) use the scalar forms.
+// Measured on MI355X at 512^3: the strided passes 0.216 -> 0.203 ms (forward) and
+// 0.193 -> 0.180 ms (inverse) with the compiler-generated packed forms alone.
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MVN_HOST_EMU) && !defined(MVN_NO_PACKED)
+#define MVN_PACKED 1
+#define MVN_PK2(r, op, a, b, mods) asm(op " %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b))
+#define MVN_PK3(r, op, a, b, c, mods) asm(op " %0, %1, %2, %3 " mods : "=v"(r) : "v"(a), "v"(b), "v"(c))
+MVN_HD cfloat cadd(cfloat a, cfloat b) { return a + b; }
+MVN_HD cfloat csub(cfloat a, cfloat b) { return a - b; }
+MVN_HD cfloat cmul(cfloat a, cfloat w) {
+  cfloat t, r;
+  MVN_PK2(t, "v_pk_mul_f32", a, w, "op_sel_hi:[0,1]");                                   // (a.x w.x, a.x w.y)
+  MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]");  // + (-a.y w.y, a.y w.x)
+  return r;
+}
+// a * conj(w)
+MVN_HD cfloat cmulc(cfloat a, cfloat w) {
+  cfloat t, r;
+  MVN_PK2(t, "v_pk_mul_f32", a, w, "op_sel_hi:[0,1] neg_hi:[0,1]");       // (a.x w.x, -a.x w.y)
+  MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1]");  // + (a.y w.y, a.y w.x)
+  return r;
+}
+MVN_HD cfloat cconj(cfloat a) { return cmake(a.x, -a.y); }
+MVN_HD cfloat cscale(cfloat a, float s) { return a * cmake(s, s); }
+// a * s + c with a real factor
+MVN_HD cfloat cfma_s(cfloat a, float s, cfloat c) { return __builtin_elementwise_fma(a, cmake(s, s), c); }
+// a + SIGN i b
+template <int SIGN>
+MVN_HD cfloat cadd_i(cfloat a, cfloat b) {
+  cfloat r;
+  if (SIGN > 0)
+    MVN_PK2(r, "v_pk_add_f32", a, b, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]");  // (a.x - b.y, a.y + b.x)
+  else
+    MVN_PK2(r, "v_pk_add_f32", a, b, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]");  // (a.x + b.y, a.y - b.x)
+  return r;
+}
+// a + conj(b), a - conj(b)
+MVN_HD cfloat cadd_c(cfloat a, cfloat b) {
+  cfloat r;
+  MVN_PK2(r, "v_pk_add_f32", a, b, "neg_hi:[0,1]");
+  return r;
+}
+MVN_HD cfloat csub_c(cfloat a, cfloat b) {
+  cfloat r;
+  MVN_PK2(r, "v_pk_add_f32", a, b, "neg_lo:[0,1]");
+  return r;
+}
+// conj(a) + SIGN i conj(b)
+template <int SIGN>
+MVN_HD cfloat cconj_add_i(cfloat a, cfloat b) {
+  cfloat r;
+  if (SIGN > 0)
+    MVN_PK2(r, "v_pk_add_f32", a, b, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]");              // (a.x + b.y, b.x - a.y)
+  else
+    MVN_PK2(r, "v_pk_add_f32", a, b, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]");  // (a.x - b.y, -a.y - b.x)
+  return r;
+}
+#else
 MVN_HD cfloat cadd(cfloat a, cfloat b) { return cmake(a.x + b.x, a.y + b.y); }
 MVN_HD cfloat csub(cfloat a, cfloat b) { return cmake(a.x - b.x, a.y - b.y); }
 MVN_HD cfloat cmul(cfloat a, cfloat b) {
   return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
+MVN_HD cfloat cmulc(cfloat a, cfloat b) {
+  return cmake(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
 MVN_HD cfloat cconj(cfloat a) { return cmake(a.x, -a.y); }
 MVN_HD cfloat cscale(cfloat a, float s) { return cmake(a.x * s, a.y * s); }
+MVN_HD cfloat cfma_s(cfloat a, float s, cfloat c) { return cmake(a.x * s + c.x, a.y * s + c.y); }
+template <int SIGN>
+MVN_HD cfloat cadd_i(cfloat a, cfloat b) {
+  return SIGN > 0 ? cmake(a.x - b.y, a.y + b.x) : cmake(a.x + b.y, a.y - b.x);
+}
+MVN_HD cfloat cadd_c(cfloat a, cfloat b) { return cmake(a.x + b.x, a.y - b.y); }
+MVN_HD cfloat csub_c(cfloat a, cfloat b) { return cmake(a.x - b.x, a.y + b.y); }
+template <int SIGN>
+MVN_HD cfloat cconj_add_i(cfloat a, cfloat b) {
+  return SIGN > 0 ? cmake(a.x + b.y, b.x - a.y) : cmake(a.x - b.y, -a.y - b.x);
+}
+#endif
+// a - SIGN i b
+template <int SIGN>
+MVN_HD cfloat csub_i(cfloat a, cfloat b) {
+  return cadd_i<-SIGN>(a, b);
+}
+// a times the twiddle of direction SIGN from the forward table entry w (SIGN > 0: its conjugate)
+template <int SIGN>
+MVN_HD cfloat cmul_dir(cfloat a, cfloat w) {
+  return SIGN < 0 ? cmul(a, w) : cmulc(a, w);
+}
 // multiply by (SIGN * i): forward transforms use SIGN = -1 (i.e. * -i)
 template <int SIGN>
 MVN_HD cfloat cmul_si(cfloat a) {
@@ -110,11 +204,11 @@ template <int SIGN>
 MVN_HD void dft3(cfloat* a) {
   const float s3 = 0.86602540378443864676f;
   cfloat t1 = cadd(a[1], a[2]);
-  cfloat m1 = cmake(a[0].x - 0.5f * t1.x, a[0].y - 0.5f * t1.y);
-  cfloat m2 = cmul_si<SIGN>(cscale(csub(a[1], a[2]), s3));
+  cfloat m1 = cfma_s(t1, -0.5f, a[0]);
+  cfloat m2 = cscale(csub(a[1], a[2]), s3);
   a[0] = cadd(a[0], t1);
-  a[1] = cadd(m1, m2);
-  a[2] = csub(m1, m2);
+  a[1] = cadd_i<SIGN>(m1, m2);
+  a[2] = csub_i<SIGN>(m1, m2);
 }
 
 template <int SIGN>
@@ -122,11 +216,11 @@ MVN_HD void dft4(cfloat* a) {
   cfloat t0 = cadd(a[0], a[2]);
   cfloat t1 = csub(a[0], a[2]);
   cfloat t2 = cadd(a[1], a[3]);
-  cfloat t3 = cmul_si<SIGN>(csub(a[1], a[3]));
+  cfloat t3 = csub(a[1], a[3]);
   a[0] = cadd(t0, t2);
-  a[1] = cadd(t1, t3);
+  a[1] = cadd_i<SIGN>(t1, t3);
   a[2] = csub(t0, t2);
-  a[3] = csub(t1, t3);
+  a[3] = csub_i<SIGN>(t1, t3);
 }
 
 template <int SIGN>
@@ -137,15 +231,15 @@ MVN_HD void dft5(cfloat* a) {
   const float s2 = 0.58778525229247312917f;   // sin(4pi/5)
   cfloat t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
   cfloat t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
-  cfloat b1 = cmake(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
-  cfloat b2 = cmake(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
-  cfloat d1 = cmul_si<SIGN>(cmake(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
-  cfloat d2 = cmul_si<SIGN>(cmake(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+  cfloat b1 = cfma_s(t2, c2, cfma_s(t1, c1, a[0]));
+  cfloat b2 = cfma_s(t2, c1, cfma_s(t1, c2, a[0]));
+  cfloat d1 = cfma_s(t4, s2, cscale(t3, s1));
+  cfloat d2 = cfma_s(t4, -s1, cscale(t3, s2));
   a[0] = cadd(a[0], cadd(t1, t2));
-  a[1] = cadd(b1, d1);
-  a[4] = csub(b1, d1);
-  a[2] = cadd(b2, d2);
-  a[3] = csub(b2, d2);
+  a[1] = cadd_i<SIGN>(b1, d1);
+  a[4] = csub_i<SIGN>(b1, d1);
+  a[2] = cadd_i<SIGN>(b2, d2);
+  a[3] = csub_i<SIGN>(b2, d2);
 }
 
 template <int SIGN>
@@ -158,25 +252,19 @@ MVN_HD void dft7(cfloat* a) {
   const float s3 = 0.43388373911755812048f;   // sin(6pi/7)
   cfloat t1 = cadd(a[1], a[6]), t2 = cadd(a[2], a[5]), t3 = cadd(a[3], a[4]);
   cfloat u1 = csub(a[1], a[6]), u2 = csub(a[2], a[5]), u3 = csub(a[3], a[4]);
-  cfloat b1 = cmake(a[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x,
-                    a[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
-  cfloat b2 = cmake(a[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x,
-                    a[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
-  cfloat b3 = cmake(a[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x,
-                    a[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
-  cfloat d1 = cmul_si<SIGN>(cmake(s1 * u1.x + s2 * u2.x + s3 * u3.x,
-                                  s1 * u1.y + s2 * u2.y + s3 * u3.y));
-  cfloat d2 = cmul_si<SIGN>(cmake(s2 * u1.x - s3 * u2.x - s1 * u3.x,
-                                  s2 * u1.y - s3 * u2.y - s1 * u3.y));
-  cfloat d3 = cmul_si<SIGN>(cmake(s3 * u1.x - s1 * u2.x + s2 * u3.x,
-                                  s3 * u1.y - s1 * u2.y + s2 * u3.y));
+  cfloat b1 = cfma_s(t3, c3, cfma_s(t2, c2, cfma_s(t1, c1, a[0])));
+  cfloat b2 = cfma_s(t3, c1, cfma_s(t2, c3, cfma_s(t1, c2, a[0])));
+  cfloat b3 = cfma_s(t3, c2, cfma_s(t2, c1, cfma_s(t1, c3, a[0])));
+  cfloat d1 = cfma_s(u3, s3, cfma_s(u2, s2, cscale(u1, s1)));
+  cfloat d2 = cfma_s(u3, -s1, cfma_s(u2, -s3, cscale(u1, s2)));
+  cfloat d3 = cfma_s(u3, s2, cfma_s(u2, -s1, cscale(u1, s3)));
   a[0] = cadd(cadd(a[0], t1), cadd(t2, t3));
-  a[1] = cadd(b1, d1);
-  a[6] = csub(b1, d1);
-  a[2] = cadd(b2, d2);
-  a[5] = csub(b2, d2);
-  a[3] = cadd(b3, d3);
-  a[4] = csub(b3, d3);
+  a[1] = cadd_i<SIGN>(b1, d1);
+  a[6] = csub_i<SIGN>(b1, d1);
+  a[2] = cadd_i<SIGN>(b2, d2);
+  a[5] = csub_i<SIGN>(b2, d2);
+  a[3] = cadd_i<SIGN>(b3, d3);
+  a[4] = csub_i<SIGN>(b3, d3);
 }
 
 template <int SIGN>
@@ -186,20 +274,18 @@ MVN_HD void dft8(cfloat* a) {
   cfloat o[4] = {a[1], a[3], a[5], a[7]};
   dft4<SIGN>(e);
   dft4<SIGN>(o);
-  // o[k] *= exp(SIGN * 2 pi i k / 8)
-  cfloat o1 = SIGN < 0 ? cmake(r * (o[1].x + o[1].y), r * (o[1].y - o[1].x))
-                       : cmake(r * (o[1].x - o[1].y), r * (o[1].y + o[1].x));
-  cfloat o2 = cmul_si<SIGN>(o[2]);
-  cfloat o3 = SIGN < 0 ? cmake(r * (o[3].y - o[3].x), -r * (o[3].x + o[3].y))
-                       : cmake(-r * (o[3].x + o[3].y), r * (o[3].x - o[3].y));
+  // o[k] *= exp(SIGN * 2 pi i k / 8); for k = 1, 3 that is +-r (o -+ i o), folded into the sums
+  //   k = 1: r (o[1] + SIGN i o[1]),   k = 3: -r (o[3] - SIGN i o[3])
+  const cfloat q1 = cadd_i<SIGN>(o[1], o[1]);
+  const cfloat q3 = csub_i<SIGN>(o[3], o[3]);
   a[0] = cadd(e[0], o[0]);
   a[4] = csub(e[0], o[0]);
-  a[1] = cadd(e[1], o1);
-  a[5] = csub(e[1], o1);
-  a[2] = cadd(e[2], o2);
-  a[6] = csub(e[2], o2);
-  a[3] = cadd(e[3], o3);
-  a[7] = csub(e[3], o3);
+  a[1] = cfma_s(q1, r, e[1]);
+  a[5] = cfma_s(q1, -r, e[1]);
+  a[2] = cadd_i<SIGN>(e[2], o[2]);
+  a[6] = csub_i<SIGN>(e[2], o[2]);
+  a[3] = cfma_s(q3, -r, e[3]);
+  a[7] = cfma_s(q3, r, e[3]);
 }
 
 template <int R, int SIGN>
@@ -237,12 +323,12 @@ MVN_HD void stage_inplace(cfloat* buf, int TP, int n, int M, unsigned Mmul, cons
     for (int j = 0; j < R; ++j) a[j] = p[j * stride];
     if (!DIF && M > 1) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = cmul(a[k], twdir<SIGN>(tw[j2 * k * twstep]));
+      for (int k = 1; k < R; ++k) a[k] = cmul_dir<SIGN>(a[k], tw[j2 * k * twstep]);
     }
     dftR<R, SIGN>(a);
     if (DIF && M > 1) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = cmul(a[k], twdir<SIGN>(tw[j2 * k * twstep]));
+      for (int k = 1; k < R; ++k) a[k] = cmul_dir<SIGN>(a[k], tw[j2 * k * twstep]);
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) p[j * stride] = a[j];

@@ -200,12 +200,12 @@ MVN_HD void fx_stage(cfloat* buf, const cfloat* tws, int tid) {
     }
     if (!DIF && M > 1) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = cmul(a[k], twdir<SIGN>(tw[k]));
+      for (int k = 1; k < R; ++k) a[k] = cmul_dir<SIGN>(a[k], tw[k]);
     }
     dftR<R, SIGN>(a);
     if (DIF && M > 1) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = cmul(a[k], twdir<SIGN>(tw[k]));
+      for (int k = 1; k < R; ++k) a[k] = cmul_dir<SIGN>(a[k], tw[k]);
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) p[fx_rowoff<PAD, R, M>(j) * TP] = a[j];
@@ -328,13 +328,19 @@ MVN_HD void fx_dft_q(qfloat* a) {
 }
 
 MVN_HD qfloat fx_qmul_c(qfloat a, cfloat w) {  // both halves times one complex factor
-  return qmake(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x, a.z * w.x - a.w * w.y,
-               a.z * w.y + a.w * w.x);
+  const cfloat lo = cmul(cmake(a.x, a.y), w), hi = cmul(cmake(a.z, a.w), w);
+  return qmake(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <int SIGN>
+MVN_HD qfloat fx_qmul_dir(qfloat a, cfloat w) {  // both halves times the twiddle of direction SIGN
+  const cfloat lo = cmul_dir<SIGN>(cmake(a.x, a.y), w), hi = cmul_dir<SIGN>(cmake(a.z, a.w), w);
+  return qmake(lo.x, lo.y, hi.x, hi.y);
 }
 
 MVN_HD qfloat fx_qmul_q(qfloat a, qfloat g) {  // half-wise complex product
-  return qmake(a.x * g.x - a.y * g.y, a.x * g.y + a.y * g.x, a.z * g.z - a.w * g.w,
-               a.z * g.w + a.w * g.z);
+  const cfloat lo = cmul(cmake(a.x, a.y), cmake(g.x, g.y)), hi = cmul(cmake(a.z, a.w), cmake(g.z, g.w));
+  return qmake(lo.x, lo.y, hi.x, hi.y);
 }
 
 template <int R>
@@ -370,12 +376,12 @@ MVN_HD void fx_stage_q(cfloat* bufc, const cfloat* tws, int tid) {
     fx_tw_row<R>(tws + fx_twoff(N, S) + j2 * fx_rs(R), tw);
     if (!DIF) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_dir<SIGN>(a[k], tw[k]);
     }
     fx_dft_q<R, SIGN>(a);
     if (DIF) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_dir<SIGN>(a[k], tw[k]);
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) p[j * M * TPQ] = a[j];
@@ -496,7 +502,7 @@ MVN_HD void fx_st_first(const StridedParams& P, long block, long base, long next
     fx_tw_row<8>(tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
     fx_dft_q<8, -1>(a);
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<-1>(tw[k]));
+    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_dir<-1>(a[k], tw[k]);
     qfloat* d = reinterpret_cast<qfloat*>(buf) + j2 * C::TPQ + q;
 #pragma unroll
     for (int k = 0; k < 8; ++k) d[k * C::M0 * C::TPQ] = a[k];
@@ -592,7 +598,7 @@ MVN_HD void fx_st_stage0_store(const StridedParams& P, long base, const cfloat* 
     cfloat tw[8];
     fx_tw_row<8>(tws + fx_twoff(N, 0) + j2 * fx_rs(8), tw);
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(a[k], twdir<+1>(tw[k]));
+    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_dir<+1>(a[k], tw[k]);
     fx_dft_q<8, +1>(a);
     cfloat* dst = P.data + base + (long)j2 * P.estride + 2 * q;
 #pragma unroll
@@ -805,12 +811,12 @@ MVN_HD void fx_stage_q_win(cfloat* bufc, const cfloat* twl, int tid) {
     fx_tw_row<R>(twl + (fx_twoff(N, S) - C::TW1) + j2 * fx_rs(R), tw);
     if (!DIF) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_dir<SIGN>(a[k], tw[k]);
     }
     fx_dft_q<R, SIGN>(a);
     if (DIF) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) a[k] = fx_qmul_c(a[k], twdir<SIGN>(tw[k]));
+      for (int k = 1; k < R; ++k) a[k] = fx_qmul_dir<SIGN>(a[k], tw[k]);
     }
 #pragma unroll
     for (int j = 0; j < R; ++j) p[j * M * TPQ] = a[j];
@@ -910,7 +916,7 @@ MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* 
     qfloat a[8];  // a local copy: a pointer into r.a would keep the whole array in memory
     a[0] = r.a[it * 8];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_c(r.a[it * 8 + k], twdir<SIGN>(tw[k]));
+    for (int k = 1; k < 8; ++k) a[k] = fx_qmul_dir<SIGN>(r.a[it * 8 + k], tw[k]);
     fx_dft_q<8, SIGN>(a);
     if (PERM) {
 #pragma unroll
@@ -1154,11 +1160,11 @@ MVN_HD void fx_r2c_post(const RowsParams& P, long r0, cfloat* buf, const cfloat*
       P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);       // Nyquist, kept in its own plane
       *pb = cconj(zm);                                     // bin H/2 pairs with itself
     } else {
-      const cfloat E = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-      const cfloat D = cmake(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-      const cfloat G = cmul(twr[k], D);
-      *pa = cadd(E, cmul_si<-1>(G));
-      *pb = cadd(cconj(E), cmul_si<-1>(cconj(G)));
+      const cfloat E = cscale(cadd_c(zk, zm), 0.5f);
+      const cfloat D = cscale(csub_c(zk, zm), 0.5f);
+      const cfloat G = cmul(D, twr[k]);
+      *pa = cadd_i<-1>(E, G);
+      *pb = cconj_add_i<-1>(E, G);
     }
   }
 }
@@ -1272,11 +1278,11 @@ MVN_HD void fx_c2r_pre(const RowsParams& P, long r0, cfloat* buf, const cfloat* 
       *pa = cmake(xk.x + xh, xk.x - xh);
       *pb = cmake(2.f * xm.x, -2.f * xm.y);  // bin H/2 pairs with itself: Z = 2 conj(X)
     } else {
-      const cfloat E = cmake(xk.x + xm.x, xk.y - xm.y);
-      const cfloat Dk = cmake(xk.x - xm.x, xk.y + xm.y);
-      const cfloat O = cmul(Dk, cconj(twr[k]));
-      *pa = cadd(E, cmul_si<+1>(O));
-      *pb = cadd(cconj(E), cmul_si<+1>(cconj(O)));
+      const cfloat E = cadd_c(xk, xm);
+      const cfloat Dk = csub_c(xk, xm);
+      const cfloat O = cmulc(Dk, twr[k]);
+      *pa = cadd_i<+1>(E, O);
+      *pb = cconj_add_i<+1>(E, O);
     }
   }
 }
@@ -1301,7 +1307,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
     cfloat tw[fx_rs(R)];
     fx_load_tw_row<R>(tws + j2 * fx_rs(R), tw);
 #pragma unroll
-    for (int k = 1; k < R; ++k) a[k] = cmul(a[k], cconj(tw[k]));
+    for (int k = 1; k < R; ++k) a[k] = cmulc(a[k], tw[k]);
     dftR<R, +1>(a);  // a[jo] = z[j2 + M*jo] = (x[2j], x[2j+1])
     const long i0 = (r0 + rho) * P.RP + 2 * j2;
     if (KEEP) {

@@ -149,22 +149,20 @@ MVN_HD void wr_pw(const WrRegs& r, const cfloat* rows, int t, cfloat* pw) {
 //   E = X[k] + conj X[H-k],  O = (X[k] - conj X[H-k]) exp(+2 pi i k / d2)
 //   Z[k] = E + i O,  Z[H-k] = conj(E) + i conj(O)
 MVN_HD void wr_pre_pair(cfloat& xk, cfloat& xm, cfloat w) {
-  const cfloat E = cmake(xk.x + xm.x, xk.y - xm.y);
-  const cfloat D = cmake(xk.x - xm.x, xk.y + xm.y);
-  const cfloat O = cmul(D, cconj(w));
-  xk = cmake(E.x - O.y, E.y + O.x);
-  xm = cmake(E.x + O.y, O.x - E.y);
+  const cfloat E = cadd_c(xk, xm);
+  const cfloat O = cmulc(csub_c(xk, xm), w);
+  xk = cadd_i<+1>(E, O);
+  xm = cconj_add_i<+1>(E, O);
 }
 
 // complex -> half-complex step on one pair: Z[k], Z[H-k] -> X[k], X[H-k]
 //   E = (Z[k] + conj Z[H-k]) / 2,  G = exp(-2 pi i k / d2) (Z[k] - conj Z[H-k]) / 2
 //   X[k] = E - i G,  X[H-k] = conj(E) - i conj(G)
 MVN_HD void wr_post_pair(cfloat& zk, cfloat& zm, cfloat w) {
-  const cfloat E = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-  const cfloat D = cmake(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-  const cfloat G = cmul(w, D);
-  zk = cmake(E.x + G.y, E.y - G.x);
-  zm = cmake(E.x - G.y, -E.y - G.x);
+  const cfloat E = cscale(cadd_c(zk, zm), 0.5f);
+  const cfloat G = cmul(cscale(csub_c(zk, zm), 0.5f), w);
+  zk = cadd_i<-1>(E, G);
+  zm = cconj_add_i<-1>(E, G);
 }
 
 // row of lane `tid` in sweep `it` of workgroup `block` (two rows per wave: one per half-wave);
@@ -205,13 +203,48 @@ constexpr bool wr_prefetch() {
   return EPI == MVN_EPI_DIVIDE || EPI == MVN_EPI_STORE;
 }
 
+// The operands of the pointwise step (view, or psi and weights) of a row are requested one SWEEP
+// ahead as well: right behind the pointwise step of the row before, whose operand registers have
+// just become free (phase C).  Requested in phase A of the row itself (MVN_WR_EPI_AHEAD=0) they are
+// one LDS stage ahead of their use, far less than a loaded HBM round trip, and every wave of the
+// SIMD waits for them in phase C.
+#ifndef MVN_WR_EPI_AHEAD
+#define MVN_WR_EPI_AHEAD 1
+#endif
+// The fused update forms cannot hold the next spectral row across phases A - C next to psi, the
+// weights and the f64 chains; they request it at the start of phase D (MVN_WR_NX_IN_D=0: at the
+// start of phase A of the row itself, consumed at once).
+#ifndef MVN_WR_NX_IN_D
+#define MVN_WR_NX_IN_D 0
+#endif
+template <int MODE, int EPI>
+constexpr bool wr_nx_in_d() {
+  return MVN_WR_NX_IN_D && MODE == MVN_WR_C2R_R2C && !wr_prefetch<EPI>();
+}
+
 template <int EPI>
+MVN_HD void wr_fetch_epi(const RowsParams& P, long row, WrRegs& r, int tid) {
+  if (row >= P.rows) return;
+  const int t = tid & 31;  // the lane finishes reals 2 (t + 32 jo), 2 (t + 32 jo) + 1 in phase C
+  if (EPI != MVN_EPI_STORE) {
+    const float* pa = (EPI == MVN_EPI_DIVIDE ? P.epi.view : P.epi.psi) + row * P.RP + 2 * t;
+#pragma unroll
+    for (int jo = 0; jo < 8; ++jo) r.ea[jo] = *reinterpret_cast<const cfloat*>(pa + 64 * jo);
+  }
+  if (EPI == MVN_EPI_UPDATE || EPI == MVN_EPI_DELTA) {
+    const float* pb = P.epi.weights + row * P.RP + 2 * t;
+#pragma unroll
+    for (int jo = 0; jo < 8; ++jo) r.eb[jo] = *reinterpret_cast<const cfloat*>(pb + 64 * jo);
+  }
+}
+
+template <int MODE, int EPI>
 MVN_HD void wr_phase_a(const RowsParams& P, long row, long next_row, cfloat* rows, WrRegs& r, int tid) {
   if (row >= P.rows) return;
   const int t = tid & 31;
   int ga, gb;
   wr_groups(t, ga, gb);
-  if (!wr_prefetch<EPI>()) wr_fetch_row(P, row, r, tid);
+  if (!wr_prefetch<EPI>() && !wr_nx_in_d<MODE, EPI>()) wr_fetch_row(P, row, r, tid);
   const qfloat a0 = r.nx[0], a1 = r.nx[1], b0 = r.nx[2], b1 = r.nx[3];
   cfloat za[4] = {cmake(a0.x, a0.y), cmake(a0.z, a0.w), cmake(a1.x, a1.y), cmake(a1.z, a1.w)};
   cfloat zb[4] = {cmake(b0.x, b0.y), cmake(b0.z, b0.w), cmake(b1.x, b1.y), cmake(b1.z, b1.w)};
@@ -252,18 +285,7 @@ MVN_HD void wr_phase_a(const RowsParams& P, long row, long next_row, cfloat* row
   }
   MVN_SCHED_FENCE();
   if (wr_prefetch<EPI>()) wr_fetch_row(P, next_row, r, tid);
-  // the operands of the pointwise step are requested now, one LDS stage ahead of their use (phase
-  // C: the lane finishes reals 2 (t + 32 jo), 2 (t + 32 jo) + 1); the row registers are free again
-  if (EPI != MVN_EPI_STORE) {
-    const float* pa = (EPI == MVN_EPI_DIVIDE ? P.epi.view : P.epi.psi) + row * P.RP + 2 * t;
-#pragma unroll
-    for (int jo = 0; jo < 8; ++jo) r.ea[jo] = *reinterpret_cast<const cfloat*>(pa + 64 * jo);
-  }
-  if (EPI == MVN_EPI_UPDATE || EPI == MVN_EPI_DELTA) {
-    const float* pb = P.epi.weights + row * P.RP + 2 * t;
-#pragma unroll
-    for (int jo = 0; jo < 8; ++jo) r.eb[jo] = *reinterpret_cast<const cfloat*>(pb + 64 * jo);
-  }
+  if (!MVN_WR_EPI_AHEAD) wr_fetch_epi<EPI>(P, row, r, tid);
 }
 
 // ---- phases B / D: the radix-8 stage with M = 4 through the LDS ---------------------------------
@@ -280,7 +302,7 @@ MVN_HD void wr_phase_mid(long row, long nrows, cfloat* rows, const cfloat* tws, 
   wr_tw1(tws, j2, tw);
   if (SIGN > 0) {  // inverse: decimation in time, twiddles first
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a[k] = cmul(a[k], cconj(tw[k]));
+    for (int k = 1; k < 8; ++k) a[k] = cmulc(a[k], tw[k]);
   }
   dftR<8, SIGN>(a);
   if (SIGN < 0) {
@@ -294,8 +316,8 @@ MVN_HD void wr_phase_mid(long row, long nrows, cfloat* rows, const cfloat* tws, 
 // ---- phase C: outermost stage (M = 32) both ways around the pointwise step ----------------------
 // MODE R2C: real row in -> forward stage.  C2R: inverse stage -> epilogue stores.  C2R_R2C: both.
 template <int MODE, int EPI>
-MVN_HD void wr_phase_c(const RowsParams& P, long row, cfloat* rows, const cfloat* tws, WrRegs& r,
-                       int tid) {
+MVN_HD void wr_phase_c(const RowsParams& P, long row, long next_row, cfloat* rows, const cfloat* tws,
+                       WrRegs& r, int tid) {
   if (row >= P.rows) return;
   const int t = tid & 31;
   cfloat* p = wr_buf(rows, tid) + t;  // wr_f(t + 32 j) = t + 36 j
@@ -311,7 +333,7 @@ MVN_HD void wr_phase_c(const RowsParams& P, long row, cfloat* rows, const cfloat
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = p[36 * j];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) a[k] = cmul(a[k], cconj(tw[k]));
+    for (int k = 1; k < 8; ++k) a[k] = cmulc(a[k], tw[k]);
     dftR<8, +1>(a);  // a[jo] = z[t + 32 jo] = (x[2 j], x[2 j + 1])
     if (MODE == MVN_WR_C2R) {
 #pragma unroll
@@ -319,6 +341,7 @@ MVN_HD void wr_phase_c(const RowsParams& P, long row, cfloat* rows, const cfloat
         mvn_epilogue_pair_t<EPI>(P.epi, P.out_real, i0 + 64 * jo, a[jo], r.ea[jo], r.eb[jo]);
         if (jo & 1) MVN_SCHED_FENCE();  // four values at a time: the f64 chains of all 16 would not fit
       }
+      if (MVN_WR_EPI_AHEAD) wr_fetch_epi<EPI>(P, next_row, r, tid);
       return;
     }
 #pragma unroll
@@ -326,6 +349,7 @@ MVN_HD void wr_phase_c(const RowsParams& P, long row, cfloat* rows, const cfloat
       a[jo] = fx_epilogue_pair_value<EPI>(P.epi, i0 + 64 * jo, a[jo], r.ea[jo], r.eb[jo]);
       if (jo & 1) MVN_SCHED_FENCE();
     }
+    if (MVN_WR_EPI_AHEAD) wr_fetch_epi<EPI>(P, next_row, r, tid);
   }
   dftR<8, -1>(a);
   if (MODE == MVN_WR_C2R_R2C) {
@@ -403,21 +427,31 @@ MVN_HD void wr_rows_body(const RowsParams& P, long block, long nblocks, cfloat* 
   cfloat* tws = lds;
   cfloat* rows = lds + WrCfg::TW;
   MVN_PHASE(ctx, (wr_copy_tables(tws, P.ax.tws, tid), wr_setup(P, r, rows, tid),
-                  (MODE != MVN_WR_R2C && wr_prefetch<EPI>()) ? wr_fetch_row(P, wr_row(block, nblocks, 0, tid), r, tid)
-                                                             : (void)0));
+                  (MODE != MVN_WR_R2C && (wr_prefetch<EPI>() || wr_nx_in_d<MODE, EPI>()))
+                      ? wr_fetch_row(P, wr_row(block, nblocks, 0, tid), r, tid)
+                      : (void)0,
+                  (MODE != MVN_WR_R2C && MVN_WR_EPI_AHEAD) ? wr_fetch_epi<EPI>(P, wr_row(block, nblocks, 0, tid), r, tid)
+                                                           : (void)0));
   const long pairs = (P.rows + 1) / 2;
   const long per_sweep = nblocks * WrCfg::WAVES;
   const long sweeps = (pairs + per_sweep - 1) / per_sweep;
   for (long it = 0; it < sweeps; ++it) {
     if (MODE != MVN_WR_R2C) {
-      MVN_WPHASE(ctx, (wr_phase_a<EPI>(P, wr_row(block, nblocks, it, tid), wr_row(block, nblocks, it + 1, tid),
-                                       rows, r, tid)));
+      MVN_WPHASE(ctx, (wr_phase_a<MODE, EPI>(P, wr_row(block, nblocks, it, tid),
+                                             wr_row(block, nblocks, it + 1, tid), rows, r, tid)));
       MVN_WPHASE(ctx, (wr_phase_mid<+1>(wr_row(block, nblocks, it, tid), P.rows, rows, tws, tid)));
     }
-    MVN_WPHASE(ctx, (wr_phase_c<MODE, EPI>(P, wr_row(block, nblocks, it, tid), rows, tws, r, tid)));
+    MVN_WPHASE(ctx, (wr_phase_c<MODE, EPI>(P, wr_row(block, nblocks, it, tid), wr_row(block, nblocks, it + 1, tid),
+                                           rows, tws, r, tid)));
     if (MODE != MVN_WR_C2R) {
-      MVN_WPHASE(ctx, (wr_phase_mid<-1>(wr_row(block, nblocks, it, tid), P.rows, rows, tws, tid)));
-      MVN_WPHASE(ctx, (wr_phase_e<EPI>(P, wr_row(block, nblocks, it, tid), rows, r, tid)));
+      MVN_WPHASE(ctx, ((wr_nx_in_d<MODE, EPI>() && MVN_WR_NX_IN_D == 1)
+                           ? wr_fetch_row(P, wr_row(block, nblocks, it + 1, tid), r, tid)
+                           : (void)0,
+                       wr_phase_mid<-1>(wr_row(block, nblocks, it, tid), P.rows, rows, tws, tid)));
+      MVN_WPHASE(ctx, ((wr_nx_in_d<MODE, EPI>() && MVN_WR_NX_IN_D == 2)
+                           ? wr_fetch_row(P, wr_row(block, nblocks, it + 1, tid), r, tid)
+                           : (void)0,
+                       wr_phase_e<EPI>(P, wr_row(block, nblocks, it, tid), rows, r, tid)));
     }
   }
 }

@@ -89,8 +89,8 @@ MVN_HD cfloat cmake(float x, float y) {
 // count of the scalar forms.  hipcc folds whole-vector negations into the modifiers but not the
 // swap-and-negate-one-half patterns (it emits v_mov + v_xor for them), hence the inline forms on
 // the device; the host emulation (and MVN_NO_PACKED builds, for A/B runs) use the scalar forms.
-// Measured on MI355X at 512^3: the strided passes 0.216 -> 0.203 ms (forward) and
-// 0.193 -> 0.180 ms (inverse) with the compiler-generated packed forms alone.
+// Measured on MI355X at 512^3 (same box, tools/ab_variants.sh): strided passes 0.209 -> 0.198 ms
+// (forward) and 0.192 -> 0.179 ms (inverse, 6.0 TB/s); the other passes within +-1.5 %.
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MVN_HOST_EMU) && !defined(MVN_NO_PACKED)
 #define MVN_PACKED 1
@@ -98,6 +98,13 @@ MVN_HD cfloat cmake(float x, float y) {
 #define MVN_PK3(r, op, a, b, c, mods) asm(op " %0, %1, %2, %3 " mods : "=v"(r) : "v"(a), "v"(b), "v"(c))
 MVN_HD cfloat cadd(cfloat a, cfloat b) { return a + b; }
 MVN_HD cfloat csub(cfloat a, cfloat b) { return a - b; }
+// Complex products stay in scalar form (two multiplies, two fused multiply-adds, all visible to the
+// instruction scheduler): as two dependent inline packed instructions (MVN_PK_MUL_ASM) the LDS-staged
+// fused dim0 pass lost 3 % at 512^3 and no pass gained.
+#ifndef MVN_PK_MUL_ASM
+MVN_HD cfloat cmul(cfloat a, cfloat b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+MVN_HD cfloat cmulc(cfloat a, cfloat b) { return cmake(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+#else
 MVN_HD cfloat cmul(cfloat a, cfloat w) {
   cfloat t, r;
   MVN_PK2(t, "v_pk_mul_f32", a, w, "op_sel_hi:[0,1]");                                   // (a.x w.x, a.x w.y)
@@ -111,6 +118,7 @@ MVN_HD cfloat cmulc(cfloat a, cfloat w) {
   MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1]");  // + (a.y w.y, a.y w.x)
   return r;
 }
+#endif
 MVN_HD cfloat cconj(cfloat a) { return cmake(a.x, -a.y); }
 MVN_HD cfloat cscale(cfloat a, float s) { return a * cmake(s, s); }
 // a * s + c with a real factor

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from libmultiviewnative_amd import native
 lib = native.lib()
-shape = (512, 512, 512)
+shape = tuple(int(x) for x in os.environ.get("AB_SHAPE", "512 512 512").split())
 rng = np.random.default_rng(0)
 view = rng.uniform(10, 20, shape).astype(np.float32)
 wts = np.full(shape, 0.5, np.float32)
@@ -32,6 +32,6 @@ for cfg in configs:
     eng.profile(False)
     eng.close()
     print(cfg, "view-iter %.3f ms" % ms, prof, flush=True)
-    for d in (0, 1):
+    for d in (() if os.environ.get("AB_NO_FFT") else (0, 1)):
         ms, per = lib.fft3_profile(shape, d, 10)
         print("   fft3 dir", d, "%.3f ms" % ms, {k: round(v, 4) for k, v in per.items()}, flush=True)

@@ -23,6 +23,8 @@ KINDS = {
     "kx_strided<512, 1>": ["axis1_inv"],
     "kx_strided<512, 2>": ["axis0_fused"],
     "kx_rows_c2r_r2c<256, 1>": ["rows_fused_div"],
+    "kw_rows<2, 1>": ["rows_fused_div"],
+    "kw_rows<2, 2>": ["rows_fused_upd"],
     "kx_rows_c2r_r2c<256, 2>": ["rows_fused_upd"],
     "kx_rows_c2r<256, 2>": ["rows_c2r"],
 }

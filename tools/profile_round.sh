@@ -13,12 +13,12 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o p -- python3 $ROOT/bench.py --
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/sq -o p -- python3 $ROOT/tools/pmc_probe.py > $OUT/sq.log 2>&1
 echo "sq pass done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_rd -o p -- python3 $ROOT/tools/pmc_probe.py > $OUT/rd.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_rd -o p --output-format csv -- python3 $ROOT/tools/pmc_probe.py > $OUT/rd.log 2>&1
 echo "fetch pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_wr -o p -- python3 $ROOT/tools/pmc_probe.py > $OUT/wr.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_wr -o p --output-format csv -- python3 $ROOT/tools/pmc_probe.py > $OUT/wr.log 2>&1
 echo "write pass done"
 cd $ROOT
 python3 tools/rocpd_stats.py stats $OUT/stats $OUT/kernel_stats.csv > /dev/null
 python3 tools/rocpd_stats.py counters $OUT/sq_counters.md "SQ counters of the hot kernels (512^3, tools/pmc_probe.py)" $OUT/sq > /dev/null
-python3 tools/rocpd_stats.py counters $OUT/traffic_counters.md "FETCH_SIZE / WRITE_SIZE per launch (KiB; read side NOT yet doubled)" $OUT/pmc_rd $OUT/pmc_wr > /dev/null
+python3 tools/pmc_summarize.py $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_traffic.json $OUT/pmc_traffic.md > /dev/null
 echo "summaries written to $OUT"

@@ -171,6 +171,17 @@ class Binding:
                 self.set_pad_mode(None)
         return out
 
+    def gpu_deconvolve_inplace(self, psi, holder, device=0):
+        """The ABI call exactly as a host program makes it: `psi` (C-contiguous float32) is updated
+        in place, the process-wide padding policy applies.  Returns the seconds spent inside the
+        call (what the reference's bench times, bench/bench_gpu_deconvolve_synthetic.cu:190-203)."""
+        import time
+        if not (psi.flags["C_CONTIGUOUS"] and psi.dtype == np.float32):
+            raise ValueError("psi must be a C-contiguous float32 array")
+        t = time.perf_counter()
+        self.l.inplace_gpu_deconvolve(fptr(psi), holder.ws, device)
+        return time.perf_counter() - t
+
     def gpu_convolution(self, image, kernel, device=0, legacy=False):
         im = np.ascontiguousarray(image, dtype=np.float32).copy()
         k = np.ascontiguousarray(kernel, dtype=np.float32)

@@ -104,6 +104,24 @@ def kernel_bytes(kind, d0, d1, d2):
     }.get(kind, 0.0), B
 
 
+class stdout_to_stderr:
+    """Route the process's stdout (file descriptor 1, C libraries included) to stderr for a while:
+    RCCL prints a version banner on stdout when its first communicator comes up, and rank 0's
+    stdout must carry the one JSON line only."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -231,6 +249,13 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         sys.exit(self_launch(args))  # the parent never touches the GPU
+    with stdout_to_stderr():  # nothing but the final JSON line may reach stdout
+        out = run_rank(args, world_env)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def run_rank(args, world_env):
 
     cfg = CONFIGS[args.config]
     shape = tuple(args.size or cfg["size"])
@@ -427,8 +452,7 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

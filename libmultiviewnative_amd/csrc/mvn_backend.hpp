@@ -48,6 +48,8 @@ void stream_sync(stream_t s);
 // make every later operation on `s` wait for event `e` (recorded on another stream)
 void stream_wait_event(stream_t s, event_t e);
 event_t event_create();
+// an event that only orders streams (no timestamps: cheaper to record and to wait on)
+event_t event_create_sync();
 void event_destroy(event_t e);
 void event_record(event_t e, stream_t s);
 void event_sync(event_t e);

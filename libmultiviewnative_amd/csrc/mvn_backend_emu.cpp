@@ -123,6 +123,7 @@ struct EmuEvent {
   std::chrono::steady_clock::time_point t;
 };
 event_t event_create() { return new EmuEvent(); }
+event_t event_create_sync() { return new EmuEvent(); }
 void event_destroy(event_t e) { delete (EmuEvent*)e; }
 void event_record(event_t e, stream_t) { ((EmuEvent*)e)->t = std::chrono::steady_clock::now(); }
 void event_sync(event_t) {}

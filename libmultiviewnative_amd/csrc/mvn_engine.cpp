@@ -368,8 +368,8 @@ static StridedParams make_strided(const DevAxis& ax, const PassGeom& g, cfloat* 
 
 void SideStream::create() {
   s = be::stream_create();
-  fork = be::event_create();
-  join = be::event_create();
+  fork = be::event_create_sync();
+  join = be::event_create_sync();
 }
 
 void SideStream::destroy() {
@@ -765,7 +765,7 @@ void Engine::reserve_views() {
   if (!upload_stream_) upload_stream_ = be::stream_create();
   staged_ev_.resize(views_.size(), nullptr);
   for (size_t v = 0; v < views_.size(); ++v)
-    if (!staged_ev_[v]) staged_ev_[v] = be::event_create();
+    if (!staged_ev_[v]) staged_ev_[v] = be::event_create_sync();
   staged_.assign(views_.size(), 0);
   pipelined_ = true;
 }

@@ -313,6 +313,11 @@ event_t event_create() {
   HIP_CHECK(hipEventCreate(&e));
   return (event_t)e;
 }
+event_t event_create_sync() {
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return (event_t)e;
+}
 void event_destroy(event_t e) {
   if (e) (void)hipEventDestroy((hipEvent_t)e);
 }

@@ -907,6 +907,23 @@ def test_config4_long_line_kernels_vs_oracle(gpu, orc):
     assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
 
 
+def test_full_size_config4_one_view_vs_oracle(gpu, orc):
+    # BASELINE.json configs[4] at its full extent on non-trivial data: 320 x 1920 x 1920, one view,
+    # one iteration (4.7 GB per stack; the dim0 = 320 fused pass, 1920-lines with 61440 tiles per
+    # launch, 614400 rows of 960 bins) against the oracle on the host cores
+    from ref_fixtures import structured_views
+    shape = (320, 1920, 1920)
+    info = gpu.plan_describe(shape)
+    assert info["fx_rows"] == 1 and info["fx_ax1"] == 1 and info["fx_ax0"] == 1
+    views, k1, k2, w, psi0 = structured_views(shape, 1, (31, 31, 31), seed=11)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
+    got = gpu.gpu_deconvolve(psi0, h)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    ref = orc.cpu_deconvolve(psi0, h, -1)
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+
+
 @pytest.mark.parametrize("shape,chunks", [((64, 64, 64), 4), ((24, 20, 18), 3), ((12, 10, 9), 5)])
 def test_chunked_simultaneous_steps_vs_oracle(gpu, orc, shape, chunks):
     # the overlapped form of the sharded step on one rank, several iterations with the spectrum of

@@ -1014,20 +1014,37 @@ struct FxRowsCfg {
 #ifndef MVN_FX_ROWS_T
 #define MVN_FX_ROWS_T 16
 #endif
-  // Long rows (H > 512): a 16-row tile would not fit, and the 8-row tile (86 KB with its tables at
-  // H = 960) leaves ONE workgroup per CU, whose load, transform and store phases then never overlap
-  // with anything (measured at 320 x 1920 x 1920: the fused passes at 3.0 / 3.7 TB/s).  These lengths
-  // use 2-row tiles instead: several small workgroups per CU (40 KB each at H = 960), which WALK over
-  // the tiles of the launch so that the 16 KB of tables are built once per workgroup, not per tile.
+  // Two tile classes.  TILED: one 16-row tile per workgroup (8 rows above H = 512), tables rebuilt
+  // per tile.  WALKING: small tiles of 2 - 8 rows, several small workgroups per CU that WALK over
+  // the tiles of the launch so that the tables (up to 16 KB) are built once per workgroup.  Which
+  // one a length uses is measured (tools/rows_tune.sh on MI355X, fused divide + fused update of
+  // d2^3 cubes, round 2):
+  //   H = 96, 128, 256                tiled wins (0.31 vs 0.27..0.33 at 320^3 is the crossover)
+  //   H = 160, 288, 320, 384, 512     walking, 4 rows: -12 % (320^3), -29 % (576^3: 2.50 -> 1.77 ms;
+  //                                   its 9-wave workgroups of 576 threads were the worst fit),
+  //                                   -9 % (640^3), -9 % (768^3), -13 % (1024^3)
+  //   H = 192                         walking, 8 rows: -18 % (384^3)
+  //   H = 480                         walking, 2 rows (2 % ahead of 4 rows at 960^3)
+  //   H >= 640                        walking, 2 rows (a 16-row tile does not fit at all, the 8-row
+  //                                   tile leaves ONE workgroup per CU: 3.0 / 3.7 TB/s at 320 x 1920 x
+  //                                   1920 in round 1)
+  // The plain r2c pass alone would prefer the tiled class for the middle lengths (+1..48 %); it runs
+  // once per call.  MVN_FX_ROWS_SMALL_T > 0 forces the walking class with that many rows for every
+  // H >= MVN_FX_ROWS_SMALL_MIN (tuning builds).
 #ifndef MVN_FX_ROWS_SMALL_MIN
-#define MVN_FX_ROWS_SMALL_MIN 513
+#define MVN_FX_ROWS_SMALL_MIN 65
 #endif
-  static constexpr bool SMALL = H >= MVN_FX_ROWS_SMALL_MIN;
-  static constexpr bool WALK = SMALL;
 #ifndef MVN_FX_ROWS_SMALL_T
-#define MVN_FX_ROWS_SMALL_T 2
+#define MVN_FX_ROWS_SMALL_T 0
 #endif
-  static constexpr int T = SMALL ? MVN_FX_ROWS_SMALL_T : (H > 512 ? 8 : ((fx_pow2(H) && H >= 128) ? MVN_FX_ROWS_T : 16));
+  static constexpr int WALK_T = (MVN_FX_ROWS_SMALL_T > 0 && H >= MVN_FX_ROWS_SMALL_MIN) ? MVN_FX_ROWS_SMALL_T
+                                : (H >= 640 || H == 480)                   ? 2
+                                : H == 192                                 ? 8
+                                : (H >= 160 && !(fx_pow2(H) && H < 512))   ? 4
+                                                                           : 0;
+  static constexpr bool SMALL = WALK_T > 0;
+  static constexpr bool WALK = SMALL;
+  static constexpr int T = SMALL ? WALK_T : (H > 512 ? 8 : ((fx_pow2(H) && H >= 128) ? MVN_FX_ROWS_T : 16));
   static constexpr int TP = T + 1;
   static constexpr int QR = H / 2;  // 16-byte chunks per spectral row (2 complex bins each)
   static constexpr int R0 = fx_radix(H, 0);

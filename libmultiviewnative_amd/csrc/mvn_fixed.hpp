@@ -663,11 +663,23 @@ struct FxFusedCfg {
   // butterfly each; 512 unless that leaves more than eight 16-byte loads per thread
   static constexpr int FULL = N * T / 8 >= 64 ? N * T / 8 : 64;
   static constexpr int NT512 = fx_pick_nt(512, FULL, N * CH, N * CH, N * CH);
-  static constexpr int NT = (NT512 > 0 && N * CH / NT512 <= 8) ? NT512 : fx_pick_nt(1024, FULL, N * CH, N * CH, N * CH);
+  // (N = 576 takes nine loads per thread on 512 threads: with the 768 threads that eight loads would
+  // mean, the 104 registers of the pass leave ONE 12-wave workgroup per CU where the LDS holds two -
+  // measured at 576^3: 0.634 ms with 768 threads, 0.498 ms with 512 threads and 32 bytes of scratch)
+#ifndef MVN_FX_FUSED_MAX_U
+#define MVN_FX_FUSED_MAX_U 9
+#endif
+#ifndef MVN_FX_FUSED_NT_CAP
+#define MVN_FX_FUSED_NT_CAP 1024
+#endif
+  static constexpr int NT = (NT512 > 0 && N * CH / NT512 <= MVN_FX_FUSED_MAX_U) ? NT512 : fx_pick_nt(MVN_FX_FUSED_NT_CAP, FULL, N * CH, N * CH, N * CH);
   static constexpr int RPT = NT / CH;  // tile rows covered by one sweep of the workgroup
   static constexpr int U = N / RPT;    // 16-byte loads per thread
+#ifndef MVN_FX_FUSED_MAX_WAVES
+#define MVN_FX_FUSED_MAX_WAVES MVN_FX_ST_MAX_WAVES
+#endif
   static constexpr int WAVES_WANTED = (S::WG_PER_CU * (NT / 64) + 3) / 4;
-  static constexpr int WAVES = WAVES_WANTED > MVN_FX_ST_MAX_WAVES ? MVN_FX_ST_MAX_WAVES : WAVES_WANTED;
+  static constexpr int WAVES = WAVES_WANTED > MVN_FX_FUSED_MAX_WAVES ? MVN_FX_FUSED_MAX_WAVES : WAVES_WANTED;
   static_assert(NT >= 64 && N % RPT == 0, "tile rows must divide");
 };
 

@@ -296,6 +296,34 @@ MVN_HD void dft8(cfloat* a) {
   a[7] = cfma_s(q3, r, e[3]);
 }
 
+// radix 9 = 3 x 3 (Cooley-Tukey inside the butterfly): 576 = 8 * 8 * 9, the padded extent of a
+// 512-block with a 31-tap PSF, runs three stages instead of four (8, 8, 3, 3).
+//   b[j][k1] = DFT3 over m of a[j + 3 m];  b[j][k1] *= w9^(j k1);  X[k1 + 3 k2] = DFT3 over j of b[j][k1]
+template <int SIGN>
+MVN_HD void dft9(cfloat* a) {
+  const cfloat w1 = cmake(0.76604444311897803520f, (SIGN < 0 ? -1.f : 1.f) * 0.64278760968653932632f);   // w9^1
+  const cfloat w2 = cmake(0.17364817766693034885f, (SIGN < 0 ? -1.f : 1.f) * 0.98480775301220805937f);   // w9^2
+  const cfloat w4 = cmake(-0.93969262078590838405f, (SIGN < 0 ? -1.f : 1.f) * 0.34202014332566873304f);  // w9^4
+  cfloat b0[3] = {a[0], a[3], a[6]};
+  cfloat b1[3] = {a[1], a[4], a[7]};
+  cfloat b2[3] = {a[2], a[5], a[8]};
+  dft3<SIGN>(b0);
+  dft3<SIGN>(b1);
+  dft3<SIGN>(b2);
+  b1[1] = cmul(b1[1], w1);
+  b1[2] = cmul(b1[2], w2);
+  b2[1] = cmul(b2[1], w2);
+  b2[2] = cmul(b2[2], w4);
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    cfloat c[3] = {b0[k1], b1[k1], b2[k1]};
+    dft3<SIGN>(c);
+    a[k1] = c[0];
+    a[k1 + 3] = c[1];
+    a[k1 + 6] = c[2];
+  }
+}
+
 template <int R, int SIGN>
 MVN_HD void dftR(cfloat* a) {
   if (R == 2) dft2<SIGN>(a);
@@ -304,10 +332,11 @@ MVN_HD void dftR(cfloat* a) {
   if (R == 5) dft5<SIGN>(a);
   if (R == 7) dft7<SIGN>(a);
   if (R == 8) dft8<SIGN>(a);
+  if (R == 9) dft9<SIGN>(a);
 }
 
 MVN_HD bool mvn_inline_radix(int r) {
-  return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8;
+  return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 9;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,6 +416,7 @@ MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& p
     case 5: stage_inplace<5, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     case 7: stage_inplace<7, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     case 8: stage_inplace<8, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 9: stage_inplace<9, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     default: {
       stage_generic<SIGN, DIF, T>(buf, alt, TP, pl.nfft, R, M, tw, tid, nthreads);
       cfloat* t = buf;

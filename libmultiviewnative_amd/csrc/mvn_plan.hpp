@@ -54,6 +54,7 @@ struct AxisPlanHost {
     while (n % 8 == 0) { f.push_back(8); n /= 8; }
     while (n % 4 == 0) { f.push_back(4); n /= 4; }
     while (n % 2 == 0) { f.push_back(2); n /= 2; }
+    while (n % 9 == 0) { f.push_back(9); n /= 9; }  // 3 x 3 register butterfly (mvn_fft_core.hpp dft9)
     for (int p = 3; (long)p * p <= n; p += 2)
       while (n % p == 0) { f.push_back(p); n /= p; }
     if (n > 1) f.push_back(n);

@@ -325,6 +325,41 @@ MVN_HD void dft9(cfloat* a) {
 }
 
 template <int R, int SIGN>
+MVN_HD void dftR(cfloat* a);
+
+// composite radices with coprime factors R1 * R2 = 6, 10, 12, 15 by the prime-factor (Good-Thomas)
+// index maps: no twiddles inside the butterfly,
+//   n = (R2 n1 + R1 n2) mod R,  k = (e1 k1 + e2 k2) mod R,  e1 = 1 mod R1 and 0 mod R2, e2 = 0 mod R1 and 1 mod R2,
+//   X[k] = DFT_R2 over n2 of ( DFT_R1 over n1 of a[n] ).
+// One stage of radix 12 instead of two of radix 4 and 3 is one LDS round trip less per direction
+// (384 = 8*8*6, 640 = 8*8*10, 768 = 8*8*12, 960 = 8*8*15: three stages each).
+constexpr int mvn_crt_unit(int r1, int r2) {  // e with e = 1 mod r1, e = 0 mod r2
+  for (int e = 0; e < r1 * r2; e += r2)
+    if (e % r1 == 1 % r1) return e;
+  return 0;
+}
+template <int R1, int R2, int SIGN>
+MVN_HD void dft_pfa(cfloat* a) {
+  constexpr int R = R1 * R2, E1 = mvn_crt_unit(R1, R2), E2 = mvn_crt_unit(R2, R1);
+  cfloat b[R2][R1];
+#pragma unroll
+  for (int n2 = 0; n2 < R2; ++n2) {
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) b[n2][n1] = a[(R2 * n1 + R1 * n2) % R];
+    dftR<R1, SIGN>(b[n2]);  // -> k1
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) {
+    cfloat c[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) c[n2] = b[n2][k1];
+    dftR<R2, SIGN>(c);  // -> k2
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) a[(E1 * k1 + E2 * k2) % R] = c[k2];
+  }
+}
+
+template <int R, int SIGN>
 MVN_HD void dftR(cfloat* a) {
   if (R == 2) dft2<SIGN>(a);
   if (R == 3) dft3<SIGN>(a);
@@ -333,10 +368,14 @@ MVN_HD void dftR(cfloat* a) {
   if (R == 7) dft7<SIGN>(a);
   if (R == 8) dft8<SIGN>(a);
   if (R == 9) dft9<SIGN>(a);
+  if (R == 6) dft_pfa<2, 3, SIGN>(a);
+  if (R == 10) dft_pfa<2, 5, SIGN>(a);
+  if (R == 12) dft_pfa<4, 3, SIGN>(a);
+  if (R == 15) dft_pfa<3, 5, SIGN>(a);
 }
 
 MVN_HD bool mvn_inline_radix(int r) {
-  return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 9;
+  return r == 2 || r == 3 || r == 4 || r == 5 || r == 6 || r == 7 || r == 8 || r == 9 || r == 10 || r == 12 || r == 15;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -417,6 +456,10 @@ MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& p
     case 7: stage_inplace<7, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     case 8: stage_inplace<8, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     case 9: stage_inplace<9, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 6: stage_inplace<6, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 10: stage_inplace<10, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 12: stage_inplace<12, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 15: stage_inplace<15, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     default: {
       stage_generic<SIGN, DIF, T>(buf, alt, TP, pl.nfft, R, M, tw, tid, nthreads);
       cfloat* t = buf;

@@ -105,14 +105,14 @@ constexpr bool fx_smooth(int n) {  // only the factors the register butterflies 
 
 constexpr int fx_nstages(int n) {
   int c = 0;
-  for (int r : {8, 4, 2, 9, 3, 5, 7})
+  for (int r : {8, 12, 4, 6, 10, 2, 15, 9, 3, 5, 7})
     while (n % r == 0) { n /= r; ++c; }
   return c;
 }
 
 constexpr int fx_radix(int n, int s) {
   int c = 0;
-  for (int r : {8, 4, 2, 9, 3, 5, 7})
+  for (int r : {8, 12, 4, 6, 10, 2, 15, 9, 3, 5, 7})
     while (n % r == 0) { if (c == s) return r; n /= r; ++c; }
   return 1;
 }

@@ -50,11 +50,10 @@ struct AxisPlanHost {
 
   static std::vector<int> factorize(int n) {
     std::vector<int> f;
-    // big inline radices first: fewer stages = fewer LDS round trips
-    while (n % 8 == 0) { f.push_back(8); n /= 8; }
-    while (n % 4 == 0) { f.push_back(4); n /= 4; }
-    while (n % 2 == 0) { f.push_back(2); n /= 2; }
-    while (n % 9 == 0) { f.push_back(9); n /= 9; }  // 3 x 3 register butterfly (mvn_fft_core.hpp dft9)
+    // big inline radices first: fewer stages = fewer LDS round trips.  The order is the one of
+    // fx_radix (mvn_fixed.hpp): the fixed-length kernels derive the same schedule at compile time.
+    for (int r : {8, 12, 4, 6, 10, 2, 15, 9})
+      while (n % r == 0) { f.push_back(r); n /= r; }
     for (int p = 3; (long)p * p <= n; p += 2)
       while (n % p == 0) { f.push_back(p); n /= p; }
     if (n > 1) f.push_back(n);

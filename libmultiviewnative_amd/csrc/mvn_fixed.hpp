@@ -289,9 +289,12 @@ struct FxStridedCfg {
   // threads: NT1 = M0 * CH would give every thread one stage-0 butterfly (on two columns); IT0 of
   // them per thread keep the workgroup at or below MVN_FX_ST_NT_TARGET threads, which leaves the
   // registers for the tile fetched ahead (see fx_strided_body)
+  // Lengths whose stage-0 work items do not fill whole waves (96, 160, 288: the padded extents of 64-,
+  // 128- and 256-blocks) round the workgroup up; the idle threads of stage 0 are guarded (RAGGED).
   static constexpr int NT1 = M0 * CH;
   static constexpr int IT0 = fx_st_it0(NT1, MVN_FX_ST_NT_TARGET);
-  static constexpr int NT = NT1 / IT0;
+  static constexpr int NT = ((NT1 / IT0 + 63) / 64) * 64;
+  static constexpr bool RAGGED = NT * IT0 != NT1;
   static constexpr int NWL = (N / RL) * CH;  // work items of the last stage
   static constexpr int ITL = (NWL + NT - 1) / NT;
   static constexpr int lds_cfloats = N * TP + fx_twsize(N);
@@ -299,9 +302,9 @@ struct FxStridedCfg {
   static constexpr int WG_PER_CU = (160 * 1024) / (int)(sizeof(cfloat) * lds_cfloats) > 0 ? (160 * 1024) / (int)(sizeof(cfloat) * lds_cfloats) : 1;
   static constexpr int WAVES_WANTED = (WG_PER_CU * (NT / 64) + 3) / 4;
   static constexpr int WAVES = WAVES_WANTED > MVN_FX_ST_MAX_WAVES ? MVN_FX_ST_MAX_WAVES : WAVES_WANTED;
-  static_assert(fx_smooth(N) && N >= 64 && N <= 2048 && N % 64 == 0, "unsupported fixed length");
+  static_assert(fx_smooth(N) && N >= 64 && N <= 2048 && N % 32 == 0, "unsupported fixed length");
   static_assert(R0 == 8 && NS >= 2 && M0 > 1 && fx_M(N, NS - 1) == 1, "unexpected radix plan");
-  static_assert(NT % 64 == 0 && NT <= 1024 && NT * IT0 == NT1, "workgroup size");
+  static_assert(NT % 64 == 0 && NT <= 1024 && (!RAGGED || IT0 == 1), "workgroup size");
   static_assert(sizeof(cfloat) * lds_cfloats <= 160 * 1024, "tile does not fit the LDS");
 };
 
@@ -439,6 +442,7 @@ MVN_HD void fx_st_fetch_first(const StridedParams& P, long base, FxStridedRegs<N
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * C::NT;
+    if (C::RAGGED && w >= C::NT1) break;
     const int q = w % C::CH, j2 = w / C::CH;
     const cfloat* src = src0 + (long)j2 * P.estride + 2 * q;
 #pragma unroll
@@ -454,7 +458,7 @@ MVN_HD void fx_st_fetch_last_at(const cfloat* tile, long estride, qfloat* dst, i
 #pragma unroll
   for (int it = 0; it < C::ITL; ++it) {
     int w = tid + it * C::NT;
-    if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;
+    if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid % C::NWL;  // clamped to a valid item: loaded, never used
     const int b = w / C::CH, q = w % C::CH;
     const cfloat* src = tile + (long)(b * C::RL) * estride + 2 * q;
 #pragma unroll
@@ -494,6 +498,7 @@ MVN_HD void fx_st_first(const StridedParams& P, long block, long base, long next
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * C::NT;
+    if (C::RAGGED && w >= C::NT1) break;
     const int q = w % C::CH, j2 = w / C::CH;
     qfloat a[8];
 #pragma unroll
@@ -590,6 +595,7 @@ MVN_HD void fx_st_stage0_store(const StridedParams& P, long base, const cfloat* 
 #pragma unroll
   for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * C::NT;
+    if (C::RAGGED && w >= C::NT1) break;
     const int q = w % CH, j2 = w / CH;
     const qfloat* s = reinterpret_cast<const qfloat*>(buf) + j2 * C::TPQ + q;
     qfloat a[8];
@@ -884,7 +890,7 @@ MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int 
 #pragma unroll
   for (int it = 0; it < ITL; ++it) {
     int w = tid + it * C::NT;
-    if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid;  // clamped: loaded, never used
+    if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid % C::NWL;  // clamped to a valid item: loaded, never used
     const int b = w / CH, q = w % CH;
     const int pos = win * C::W + b * RL;
     long off = (long)(PERM ? fx_rev<N>(pos) : pos) * P.estride + 2 * q;
@@ -1036,6 +1042,7 @@ struct FxRowsCfg {
   //                                   its 9-wave workgroups of 576 threads were the worst fit),
   //                                   -9 % (640^3), -9 % (768^3), -13 % (1024^3)
   //   H = 192                         walking, 8 rows: -18 % (384^3)
+  //   H = 48, 80, 144                 walking, 8 rows (d2 = 96, 160, 288: no whole-wave tiled geometry)
   //   H = 480                         walking, 2 rows (2 % ahead of 4 rows at 960^3)
   //   H >= 640                        walking, 2 rows (a 16-row tile does not fit at all, the 8-row
   //                                   tile leaves ONE workgroup per CU: 3.0 / 3.7 TB/s at 320 x 1920 x
@@ -1051,7 +1058,7 @@ struct FxRowsCfg {
 #endif
   static constexpr int WALK_T = (MVN_FX_ROWS_SMALL_T > 0 && H >= MVN_FX_ROWS_SMALL_MIN) ? MVN_FX_ROWS_SMALL_T
                                 : (H >= 640 || H == 480)                   ? 2
-                                : H == 192                                 ? 8
+                                : (H == 192 || H == 144 || H == 80 || H == 48) ? 8
                                 : (H >= 160 && !(fx_pow2(H) && H < 512))   ? 4
                                                                            : 0;
   static constexpr bool SMALL = WALK_T > 0;

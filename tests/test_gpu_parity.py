@@ -98,7 +98,8 @@ def test_fixed_kernels_forward_and_roundtrip(gpu, shape):
     assert np.abs(back - x).max() < 2e-5
 
 
-MIXED_FIXED_SHAPES = {(64, 192, 384): (1, 1, 1), (320, 64, 640): (1, 1, 1), (64, 576, 192): (1, 1, 1),
+MIXED_FIXED_SHAPES = {(96, 160, 288): (1, 1, 1), (288, 96, 160): (1, 1, 1), (160, 288, 96): (1, 1, 1),
+                      (64, 192, 384): (1, 1, 1), (320, 64, 640): (1, 1, 1), (64, 576, 192): (1, 1, 1),
                       (2, 1920, 1920): (1, 1, 0), (1280, 16, 64): (1, 0, 1), (960, 16, 576): (1, 0, 1),
                       (768, 16, 960): (1, 0, 1), (640, 384, 64): (1, 1, 1), (16, 64, 1536): (1, 1, 0),
                       (16, 64, 1280): (1, 1, 0)}

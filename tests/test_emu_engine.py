@@ -602,6 +602,15 @@ def test_memory_heuristic_counts_the_cached_engine(tmp_path):
     assert "memory constraints" in r.stderr
 
 
+def test_padded_extents_of_common_blocks_have_fixed_kernels(emu):
+    # where 64-, 128-, 256- and 512-blocks land with a 31-tap PSF under the default policy: the
+    # smallest smooth length, because each of them has compile-time kernels on every axis
+    from ref_fixtures import expected_good_extent
+    for block, want in ((64, 96), (128, 160), (256, 288), (512, 576)):
+        for last in (False, True):
+            assert expected_good_extent(emu, block + 31 - 1, last) == want, (block, last)
+
+
 def test_default_padding_policy_on_a_block(emu):
     # the library default (zero_padd with FFT-friendly extents, stacks embedded / cropped by
     # strided device copies): oracle on hand-padded stacks of the same extents, guard on

@@ -393,9 +393,9 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t 
 #pragma omp for schedule(static)
     for (long b = 0; b < nblocks; ++b) {
       cfloat* l = (cfloat*)lds.data();
-      if (mode == MVN_ST_FWD) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_FWD, TT>(p, b, 0, 1, l))); }
-      if (mode == MVN_ST_INV) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_INV, TT>(p, b, 0, 1, l))); }
-      if (mode == MVN_ST_FWD_MUL_INV) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_FWD_MUL_INV, TT>(p, b, 0, 1, l))); }
+      if (mode == MVN_ST_FWD) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_FWD, TT, true>(p, b, 0, 1, l))); }
+      if (mode == MVN_ST_INV) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_INV, TT, true>(p, b, 0, 1, l))); }
+      if (mode == MVN_ST_FWD_MUL_INV) { MVN_DISPATCH_T(p.T, (strided_body<MVN_ST_FWD_MUL_INV, TT, true>(p, b, 0, 1, l))); }
     }
   }
 }

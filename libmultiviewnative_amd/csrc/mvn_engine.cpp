@@ -93,7 +93,7 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 // DevAxis / Plan3D
 // ---------------------------------------------------------------------------------------------
-DevAxis::DevAxis(int n) : host(n) {
+DevAxis::DevAxis(int n, bool composite) : host(n, composite) {
   auto upload = [](const void* src, size_t bytes) -> void* {
     void* d = be::dmalloc(bytes);
     be::h2d(d, src, bytes, nullptr);
@@ -175,8 +175,27 @@ PassGeom Plan3D::pick_geom(int n, bool generic, bool rows, int max_t) {
   return g;
 }
 
+// which axes run the fixed-length kernels: known from the extents alone, and needed before the
+// axis plans are built (the fixed kernels have their own radix schedule, see AxisPlanHost::factorize)
+static bool fixed_allowed() { return env_int("MVN_NO_FIXED", 0) == 0; }
+static bool rows_fixed(const Layout& L) {
+  int T = 0, threads = 0;
+  size_t lds = 0;
+  return fixed_allowed() && L.even && fixed_rows_geom(L.h, &T, &threads, &lds) && L.rows % (size_t)T == 0;
+}
+static bool ax1_fixed(const Layout& L) {
+  int T = 0, threads = 0;
+  size_t lds = 0;
+  return fixed_allowed() && fixed_strided_geom(L.d1, &T, &threads, &lds) && L.C % T == 0;
+}
+static bool ax0_fixed(const Layout& L) {
+  int T = 0, threads = 0;
+  size_t lds = 0;
+  return fixed_allowed() && fixed_strided_geom(L.d0, &T, &threads, &lds) && ((long)L.d1 * L.C) % T == 0;
+}
+
 Plan3D::Plan3D(int dev, int d0, int d1, int d2)
-    : device(dev), L(d0, d1, d2), ax2(L.h), ax1(d1), ax0(d0) {
+    : device(dev), L(d0, d1, d2), ax2(L.h, rows_fixed(L)), ax1(d1, ax1_fixed(L)), ax0(d0, ax0_fixed(L)) {
   if (L.even) {
     std::vector<cfloat> roots((size_t)L.h / 2 + 1);
     for (size_t k = 0; k < roots.size(); ++k) {
@@ -197,23 +216,26 @@ Plan3D::Plan3D(int dev, int d0, int d1, int d2)
   g_ax0f = pick_geom(ax0.host.nfft, ax0.host.generic, false, env_int("MVN_T_FUSED", 16));
   g_nyq1 = g_ax1;
   g_nyq0 = g_ax0;
-  // fixed-length fast path: power-of-two line, full tiles, 16-byte aligned rows
-  if (env_int("MVN_NO_FIXED", 0) == 0) {
+  // fixed-length fast path: full tiles, 16-byte aligned rows
+  {
     int T = 0, threads = 0;
     size_t lds = 0;
-    if (L.even && fixed_rows_geom(L.h, &T, &threads, &lds) && L.rows % (size_t)T == 0) {
+    if (rows_fixed(L)) {
+      fixed_rows_geom(L.h, &T, &threads, &lds);
       fx_rows = true;
       gx_rows.T = T;
       gx_rows.threads = threads;
       gx_rows.lds_bytes = lds;
     }
-    if (fixed_strided_geom(d1, &T, &threads, &lds) && L.C % T == 0) {
+    if (ax1_fixed(L)) {
+      fixed_strided_geom(d1, &T, &threads, &lds);
       fx_ax1 = true;
       gx_ax1.T = gx_ax1.TP = T;
       gx_ax1.threads = threads;
       gx_ax1.lds_bytes = lds;
     }
-    if (fixed_strided_geom(d0, &T, &threads, &lds) && ((long)L.d1 * L.C) % T == 0) {
+    if (ax0_fixed(L)) {
+      fixed_strided_geom(d0, &T, &threads, &lds);
       fx_ax0 = true;
       gx_ax0.T = gx_ax0.TP = T;
       gx_ax0.threads = threads;

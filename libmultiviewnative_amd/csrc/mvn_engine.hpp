@@ -71,7 +71,7 @@ struct DevAxis {
   int* rev = nullptr;
   int* inv = nullptr;
   AxisPlan view;
-  explicit DevAxis(int n);
+  explicit DevAxis(int n, bool composite = false);
   ~DevAxis();
   DevAxis(const DevAxis&) = delete;
   DevAxis& operator=(const DevAxis&) = delete;

@@ -442,7 +442,11 @@ MVN_HD void stage_generic(const cfloat* in, cfloat* out, int TP, int n, int R, i
   }
 }
 
-template <int SIGN, bool DIF, int T>
+// COMP: the launch may meet the composite radices 6, 10, 12, 15 (only the fixed-length schedules
+// contain them: the Nyquist-plane launches that accompany the fixed kernels).  The main run-time-
+// radix kernels are compiled without those cases: their register allocation is the maximum over
+// all cases, and radix 15 cost the 560^3 view update 15 %.
+template <int SIGN, bool DIF, int T, bool COMP = false>
 MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, int s,
                            const cfloat* tw, int tid, int nthreads) {
   const int R = pl.radix[s];
@@ -456,10 +460,12 @@ MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& p
     case 7: stage_inplace<7, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     case 8: stage_inplace<8, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
     case 9: stage_inplace<9, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
-    case 6: stage_inplace<6, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
-    case 10: stage_inplace<10, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
-    case 12: stage_inplace<12, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
-    case 15: stage_inplace<15, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break;
+    case 6: if constexpr (COMP) { stage_inplace<6, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break; }
+    case 10: if constexpr (COMP) { stage_inplace<10, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break; }
+    case 12: if constexpr (COMP) { stage_inplace<12, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break; }
+    case 15: if constexpr (COMP) { stage_inplace<15, SIGN, DIF, T>(buf, TP, pl.nfft, M, mm, tw, tid, nthreads); break; }
+    // (without COMP these fall through to the out-of-place stage, which is never reached:
+    // schedules with composite radices are only built for axes that run fixed kernels)
     default: {
       stage_generic<SIGN, DIF, T>(buf, alt, TP, pl.nfft, R, M, tw, tid, nthreads);
       cfloat* t = buf;
@@ -473,21 +479,21 @@ MVN_HD void stage_dispatch(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& p
 // the buffer that holds the result (it flips to `alt` once per generic stage).  The caller must
 // have synchronised the tile before the call; the tile is synchronised on return.  `tw` may
 // point to an LDS copy of the plan's twiddle table.
-template <int SIGN, int T>
+template <int SIGN, int T, bool COMP = false>
 MVN_HD void lds_radix_dif(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
                           int tid, int nthreads) {
   for (int s = 0; s < pl.nstages; ++s) {
-    stage_dispatch<SIGN, true, T>(buf, alt, TP, pl, s, tw, tid, nthreads);
+    stage_dispatch<SIGN, true, T, COMP>(buf, alt, TP, pl, s, tw, tid, nthreads);
     MVN_SYNC();
   }
 }
 
 // Reverse-order stages: position p holds x[rev[p]] on entry -> natural order out.
-template <int SIGN, int T>
+template <int SIGN, int T, bool COMP = false>
 MVN_HD void lds_radix_dit(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
                           int tid, int nthreads) {
   for (int s = pl.nstages - 1; s >= 0; --s) {
-    stage_dispatch<SIGN, false, T>(buf, alt, TP, pl, s, tw, tid, nthreads);
+    stage_dispatch<SIGN, false, T, COMP>(buf, alt, TP, pl, s, tw, tid, nthreads);
     MVN_SYNC();
   }
 }
@@ -498,7 +504,7 @@ MVN_HD void lds_radix_dit(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl
 // decimation-in-frequency, multiply by the pre-transformed chirp in position order, inverse
 // decimation-in-time).  SIGN = +1 runs the same tables on conjugated data.  Input and output are
 // both in natural order: bluestein axes have identity rev/inv tables.
-template <int SIGN, int T>
+template <int SIGN, int T, bool COMP = false>
 MVN_HD void lds_bluestein(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
                           int tid, int nthreads) {
   const int n = pl.n, m = pl.nfft;
@@ -513,13 +519,13 @@ MVN_HD void lds_bluestein(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl
     buf[j * TP + c] = v;
   }
   MVN_SYNC();
-  lds_radix_dif<-1, T>(buf, alt, TP, pl, tw, tid, nthreads);
+  lds_radix_dif<-1, T, COMP>(buf, alt, TP, pl, tw, tid, nthreads);
   for (int w = tid; w < m * T; w += nthreads) {
     const int p = w / T, c = w % T;
     buf[p * TP + c] = cmul(buf[p * TP + c], pl.bhat[p]);
   }
   MVN_SYNC();
-  lds_radix_dit<+1, T>(buf, alt, TP, pl, tw, tid, nthreads);
+  lds_radix_dit<+1, T, COMP>(buf, alt, TP, pl, tw, tid, nthreads);
   for (int w = tid; w < n * T; w += nthreads) {
     const int k = w / T, c = w % T;
     cfloat v = cmul(buf[k * TP + c], pl.chirp[k]);
@@ -530,21 +536,21 @@ MVN_HD void lds_bluestein(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl
 }
 
 // The transforms the pass bodies call: radix stages, or the chirp-z route for awkward lengths.
-template <int SIGN, int T>
+template <int SIGN, int T, bool COMP = false>
 MVN_HD void lds_fft_dif(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
                         int tid, int nthreads) {
   if (pl.bluestein)
-    lds_bluestein<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+    lds_bluestein<SIGN, T, COMP>(buf, alt, TP, pl, tw, tid, nthreads);
   else
-    lds_radix_dif<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+    lds_radix_dif<SIGN, T, COMP>(buf, alt, TP, pl, tw, tid, nthreads);
 }
-template <int SIGN, int T>
+template <int SIGN, int T, bool COMP = false>
 MVN_HD void lds_fft_dit(cfloat*& buf, cfloat*& alt, int TP, const AxisPlan& pl, const cfloat* tw,
                         int tid, int nthreads) {
   if (pl.bluestein)
-    lds_bluestein<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+    lds_bluestein<SIGN, T, COMP>(buf, alt, TP, pl, tw, tid, nthreads);
   else
-    lds_radix_dit<SIGN, T>(buf, alt, TP, pl, tw, tid, nthreads);
+    lds_radix_dit<SIGN, T, COMP>(buf, alt, TP, pl, tw, tid, nthreads);
 }
 
 // copy the plan's twiddle table into LDS (stage loops then read it with broadcast ds_reads

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(512) k_rows_c2r_r2c(const RowsParams p) {
 template <int MODE, int T, bool NYQ>
 __global__ void __launch_bounds__(512) k_strided(const StridedParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
-  strided_body<MODE, T>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+  strided_body<MODE, T, NYQ>(p, (long)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
 }
 
 // ---- compile-time specialised kernels for power-of-two lengths (mvn_fixed.hpp) ----------------

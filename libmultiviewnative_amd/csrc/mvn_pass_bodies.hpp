@@ -511,7 +511,7 @@ struct StridedParams {
 // operands up front and keeps them in registers across the forward transform.
 #define MVN_STRIDED_U 8
 
-template <int MODE, int T>
+template <int MODE, int T, bool COMP = false>
 MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthreads, cfloat* lds) {
   constexpr int U = MVN_STRIDED_U;
   const int n = P.ax.n, TP = P.TP;
@@ -558,9 +558,9 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
   }
   MVN_SYNC();
   if (MODE == MVN_ST_INV) {
-    lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
+    lds_fft_dit<+1, T, COMP>(buf, alt, TP, P.ax, tw, tid, nthreads);
   } else {
-    lds_fft_dif<-1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
+    lds_fft_dif<-1, T, COMP>(buf, alt, TP, P.ax, tw, tid, nthreads);
     if (MODE == MVN_ST_FWD_MUL_INV) {
       if (single) {
 #pragma unroll
@@ -592,7 +592,7 @@ MVN_HD void strided_body(const StridedParams& P, long block, int tid, int nthrea
         }
       }
       MVN_SYNC();
-      lds_fft_dit<+1, T>(buf, alt, TP, P.ax, tw, tid, nthreads);
+      lds_fft_dit<+1, T, COMP>(buf, alt, TP, P.ax, tw, tid, nthreads);
     }
   }
   for (int w = tid; w < total; w += nthreads) {

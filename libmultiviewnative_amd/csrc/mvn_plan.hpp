@@ -48,19 +48,28 @@ struct AxisPlanHost {
   bool generic = false;
   int max_generic_radix = 0;
 
-  static std::vector<int> factorize(int n) {
+  // `composite`: the schedule of the fixed-length kernels (fx_radix, mvn_fixed.hpp), which adds the
+  // register butterflies 12, 6, 10, 15 (prime-factor maps) to the run-time-radix schedule.  Axes
+  // that run the run-time-radix kernels keep the plain schedule: those kernels are compiled without
+  // the composite cases.
+  static std::vector<int> factorize(int n, bool composite = false) {
     std::vector<int> f;
-    // big inline radices first: fewer stages = fewer LDS round trips.  The order is the one of
-    // fx_radix (mvn_fixed.hpp): the fixed-length kernels derive the same schedule at compile time.
-    for (int r : {8, 12, 4, 6, 10, 2, 15, 9})
-      while (n % r == 0) { f.push_back(r); n /= r; }
+    // big inline radices first: fewer stages = fewer LDS round trips
+    if (composite) {
+      for (int r : {8, 12, 4, 6, 10, 2, 15, 9})
+        while (n % r == 0) { f.push_back(r); n /= r; }
+    } else {
+      for (int r : {8, 4, 2, 9})
+        while (n % r == 0) { f.push_back(r); n /= r; }
+    }
     for (int p = 3; (long)p * p <= n; p += 2)
       while (n % p == 0) { f.push_back(p); n /= p; }
     if (n > 1) f.push_back(n);
     return f;
   }
 
-  explicit AxisPlanHost(int n_) : n(n_) {
+  bool composite = false;
+  explicit AxisPlanHost(int n_, bool composite_ = false) : n(n_), composite(composite_) {
     if (n < 1) throw std::invalid_argument("mvn: FFT length must be >= 1");
     nfft = n;
     {
@@ -84,7 +93,7 @@ struct AxisPlanHost {
   // radix schedule, strides, twiddles and position tables of a length-`len` radix transform
   void build_radix_tables(int len) {
     const int n = len;  // shadows the member on purpose: everything below is about `len`
-    radix = factorize(n);
+    radix = factorize(n, composite);
     if (radix.empty()) radix.push_back(1);  // n == 1: a single no-op "radix-1" generic stage
     if ((int)radix.size() > MVN_MAX_STAGES)
       throw std::invalid_argument("mvn: too many radix stages for length " + std::to_string(n));

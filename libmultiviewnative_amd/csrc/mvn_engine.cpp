@@ -920,8 +920,13 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   e2.min_value = min_value;
 
   // convolution 1: psi (*) kernel1
+  // The Nyquist-plane launches run on a second stream under the full-volume passes - except for
+  // small volumes, where the two event waits per convolution cost more than three more 4 us
+  // launches in line (measured per view update: 64^3 0.095 -> 0.074 ms, 96^3 0.124 -> 0.105 ms,
+  // 128^3 0.143 -> 0.134 ms in line; 256^3 0.308 -> 0.340 ms, so the switch sits in between).
   static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;  // A/B knob
-  SideStream* side = no_side ? nullptr : &side_;
+  static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
+  SideStream* side = (no_side || P.main_bytes() <= side_min_bytes) ? nullptr : &side_;
   if (!work_has_psi_spectrum_) P.rows_r2c(psi_, W, work_nyq_, stream_, prof);
   work_has_psi_spectrum_ = false;
   P.middle_passes(W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, side, spec_tiled_);
@@ -1073,7 +1078,8 @@ void Engine::compute_delta_head(double lambda, float min_value) {
   static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;
   const bool fuse = P.can_fuse_rows() && !no_fuse;
   static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;
-  const bool use_side = !no_side && side_.s && P.L.even;
+  static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
+  const bool use_side = !no_side && side_.s && P.L.even && P.main_bytes() > side_min_bytes;
   be::stream_t sn = use_side ? side_.s : stream_;
   if (!psi_spec_valid_) {  // else: left there chunk by chunk by apply_delta_chunk(.., feed_next)
     P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);

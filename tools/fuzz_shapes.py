@@ -14,11 +14,14 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 pool = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 16, 17, 20, 24, 25, 27, 31, 32, 33, 36, 40, 48, 49, 62, 64,
         66, 72, 80, 96, 100, 127, 128, 130, 160, 192, 256]
+if os.environ.get("FUZZ_FIXED"):  # mostly lengths with compile-time kernels, mixed over the three axes
+    pool = [64, 96, 128, 160, 192, 256, 288, 320, 384, 512, 576, 640, 48, 30, 18]
+pad_mode = os.environ.get("FUZZ_PAD", "none")  # "zero": the default policy, oracle on hand-padded stacks
 worst = 0.0
 for i in range(n):
     while True:
         shape = tuple(int(rng.choice(pool)) for _ in range(3))
-        if np.prod(shape) <= 3_000_000:
+        if np.prod(shape) <= int(os.environ.get("FUZZ_MAX_VOXELS", "3000000")):
             break
     V = int(rng.integers(1, 4))
     ks = tuple(int(min(s, rng.choice([1, 2, 3, 4, 5, 7]))) for s in shape)

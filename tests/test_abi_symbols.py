@@ -73,3 +73,18 @@ def test_struct_layout_matches_jna():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(native.MvnError):
         native.Binding(str(tmp_path / "nope.so"))
+
+
+def test_bench_keeps_foreign_output_off_stdout():
+    # bench.py's contract is ONE JSON line on stdout; libraries that print there (RCCL's version
+    # banner) are routed to stderr by bench.stdout_to_stderr, C-level writes included
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "with bench.stdout_to_stderr():\n"
+            "    print('python-level noise'); os.write(1, b'c-level noise\\n')\n"
+            "print('{\"ok\": true}')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == '{"ok": true}', r.stdout
+    assert "python-level noise" in r.stderr and "c-level noise" in r.stderr

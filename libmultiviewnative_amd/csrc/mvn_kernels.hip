@@ -484,8 +484,14 @@ static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
   return !off && (mask & kind_bit) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
 }
 
+// `mult_default` workgroups per resident slot: short-lived workgroups that the dispatcher keeps
+// feeding in address order stream better than resident ones that walk (tools/skeleton_probe.hip: a
+// bare 2-reads-1-write skeleton reaches 5.27 TB/s with resident walkers, 5.50 with 64 workgroups per
+// slot, 5.84 one-shot); against that the tables are built once per workgroup.  Measured at 512^3
+// (tools/ab_bench.sh): fused divide 0.336 -> 0.312 ms at 16 per slot, fused update 0.535 -> 0.498 ms
+// at 32; MVN_WR_GRID_MULT overrides both.
 template <typename K>
-static void launch_wave_rows(K kernel, const RowsParams& p, stream_t s) {
+static void launch_wave_rows(K kernel, const RowsParams& p, stream_t s, long mult_default = 16) {
   static const size_t pad = [] {  // experiment knob: extra LDS per workgroup = fewer resident workgroups
     const char* e = std::getenv("MVN_WR_LDS_PAD_KB");
     return (size_t)(e && *e ? std::atoi(e) : 0) * 1024;
@@ -493,8 +499,13 @@ static void launch_wave_rows(K kernel, const RowsParams& p, stream_t s) {
   const size_t lds = sizeof(cfloat) * (size_t)WrCfg::lds_cfloats + pad;
   const long pairs = (p.rows + 1) / 2;
   long grid = (pairs + WrCfg::WAVES - 1) / WrCfg::WAVES;
+  static const long mult_env = [] {
+    const char* e = std::getenv("MVN_WR_GRID_MULT");
+    return (long)(e && *e ? std::atoi(e) : 0);
+  }();
+  const long mult = mult_env > 0 ? mult_env : mult_default;
   const long resident = (long)resident_per_cu(reinterpret_cast<const void*>(kernel), WrCfg::NT, lds) *
-                        device_cu_count();
+                        device_cu_count() * mult;
   if (grid > resident) grid = resident;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WrCfg::NT), lds, hs(s), p);
   HIP_CHECK(hipGetLastError());
@@ -505,8 +516,14 @@ static void launch_rows_fixed(K kernel, const RowsParams& p, long nblocks, int n
                               stream_t s) {
   if (WALK) {
     ensure_lds(kernel, lds_bytes);
+    // eight workgroups per resident slot (see launch_wave_rows): measured fused divide / update
+    // -5 / -3 % at 576^3, -7 / -7 % at 320 x 1920 x 1920 against resident walkers
+    static const long mult = [] {
+      const char* e = std::getenv("MVN_ROWS_GRID_MULT");
+      return (long)(e && *e && std::atoi(e) > 0 ? std::atoi(e) : 8);
+    }();
     const long resident = (long)resident_per_cu(reinterpret_cast<const void*>(kernel), nthreads, lds_bytes) *
-                          device_cu_count();
+                          device_cu_count() * mult;
     if (nblocks > resident) nblocks = resident;
   }
   launch_pass(kernel, p, nblocks, nthreads, lds_bytes, s);
@@ -595,7 +612,7 @@ void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t
   if (wave_rows_enabled(p, p.epi.mode == MVN_EPI_DIVIDE ? 4 : 8)) {
     switch (p.epi.mode) {
       case MVN_EPI_DIVIDE: return launch_wave_rows(kw_rows<MVN_WR_C2R_R2C, MVN_EPI_DIVIDE>, p, s);
-      case MVN_EPI_UPDATE: return launch_wave_rows(kw_rows<MVN_WR_C2R_R2C, MVN_EPI_UPDATE>, p, s);
+      case MVN_EPI_UPDATE: return launch_wave_rows(kw_rows<MVN_WR_C2R_R2C, MVN_EPI_UPDATE>, p, s, 32);
       default: return launch_wave_rows(kw_rows<MVN_WR_C2R_R2C, MVN_EPI_STORE>, p, s);
     }
   }

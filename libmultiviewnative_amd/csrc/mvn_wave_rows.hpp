@@ -94,8 +94,12 @@ MVN_HD cfloat wr_root(const cfloat* twr, int k) {
 MVN_HD void wr_copy_tables(cfloat* dst, const cfloat* src, int tid) {
   constexpr int S1 = fx_twoff(WrCfg::H, 1);  // 32 rows of 8 (stage 0), then 4 rows of 8 (stage 1)
   static_assert(S1 == 256 && WrCfg::TW == 288, "twiddle table of 256 = 8 * 8 * 4");
-  for (int i = tid; i < WrCfg::TW; i += WrCfg::NT) {
-    const int d = i < S1 ? (i & 7) * 32 + (i >> 3) : S1 + ((i - S1) & 7) * 4 + ((i - S1) >> 3);
+  // neighbouring lanes write neighbouring LDS words (the gather is on the global side, where it
+  // costs nothing: the table is 2.3 KB of L2-resident data); the other way round the stores of a
+  // half-wave hit one bank group, which showed in the conflict counters once a launch had 16x more
+  // workgroups
+  for (int d = tid; d < WrCfg::TW; d += WrCfg::NT) {
+    const int i = d < S1 ? (d & 31) * 8 + (d >> 5) : S1 + ((d - S1) & 3) * 8 + ((d - S1) >> 2);
     dst[d] = src[i];
   }
 }

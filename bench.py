@@ -422,6 +422,26 @@ def run_rank(args, world_env):
             actual = 22.0 * vol * V / (ms_per_step * 1e-3) / 1e9
             out["whole_step_GBps_actual_22vol"] = round(actual, 1)
             out["whole_step_actual_frac_of_8TBps"] = round(actual / HBM_PEAK_GBS, 4)
+        # The N > 1 lines time the simultaneous (Jacobi) loop, this line's `value` the reference-order
+        # sequential sweep: a scaling series must be read against the SAME loop on one rank, so the
+        # N = 1 line carries that rate too (same engine, same stacks, same step count).
+        if world == 1 and driver is None and not args.no_side:
+            jac = SimultaneousDriver(eng, None, None)
+            jac.run(max(1, args.warmup), LAMBDA, MIN_VALUE)
+            eng.sync()
+            t1 = time.perf_counter()
+            jac.run(args.steps, LAMBDA, MIN_VALUE)
+            eng.sync()
+            dt = time.perf_counter() - t1
+            out["scaling_baseline"] = {
+                "update_mode": "simultaneous (Jacobi), single rank: the loop the N > 1 lines run, on one GPU",
+                "value": round(args.steps / dt, 4), "unit": "iterations/s",
+                "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "note": "speed-up of an N > 1 line = its value / this value; `value` above is the sequential "
+                        "(Gauss-Seidel, reference-order) sweep and stays the headline"}
+        elif use_dist:
+            out["scaling_relative_to"] = ("the N = 1 line's scaling_baseline.value (the same Jacobi loop on one "
+                                          "rank), not its headline value (sequential sweep)")
     if use_dist:
         eng.bind_delta(None)
     eng.close()

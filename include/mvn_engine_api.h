@@ -28,6 +28,9 @@ MVN_API int mvn_release_cached_engines(void);
  * (exactly image + kernel - 1), "none" (the reference CPU path's cyclic no_padd); NULL or ""
  * returns to the environment variable MVN_PAD_MODE / the default.  See multiviewnative.h. */
 MVN_API int mvn_set_pad_mode(const char* mode);
+/* The mode last selected with mvn_set_pad_mode ("zero" | "zero_exact" | "none"), or "" when the
+ * environment / default decides -- what a caller that switches the policy for one call restores. */
+MVN_API const char* mvn_get_pad_mode(void);
 /* A resident engine keeps, per view slot, the PSF spectra of the last call together with host
  * copies of the kernels they were made from; a call (or mvn_engine_set_view) that brings
  * bytewise identical kernels for a slot re-uses the spectra (the reference's

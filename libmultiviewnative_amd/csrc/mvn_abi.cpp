@@ -93,11 +93,13 @@ static std::unique_ptr<Engine> pop_cached_engine(int dev) {
 }
 
 // caller holds device_mutex(dev).  The memory heuristic of src/multiviewnative.cu:94-119, restated
-// for the resident layout (4 volumes per view -- view, weights, two spectra -- + psi + work, + 2 %
-// slack), is applied only when the call has to allocate: a cached engine of the same shape is
-// re-used as it is (its memory is what the check would ask for), and a stale one of another shape
-// is freed BEFORE the free memory is read.
-static std::unique_ptr<Engine> take_engine(int dev, const shape_t& ext, int V) {
+// for the resident layout (4 volumes per view -- view, weights, two spectra -- + psi + work + the
+// spectrum scratch of the PSF preparation, + the host-shaped embedding scratch of the padded
+// policies, + 2 % slack), is applied only when the call has to allocate: a cached engine of the same
+// shape is re-used as it is (its memory is what the check would ask for), and a stale one of another
+// shape is freed BEFORE the free memory is read -- so that "does not fit" is said here, before any
+// work is queued, not by a failing hipMalloc on the staging thread.
+static std::unique_ptr<Engine> take_engine(int dev, const shape_t& ext, int V, size_t embed_floats) {
   std::unique_ptr<Engine> e = pop_cached_engine(dev);
   if (e && engine_cache_enabled()) {
     const Layout& L = e->layout();
@@ -105,7 +107,7 @@ static std::unique_ptr<Engine> take_engine(int dev, const shape_t& ext, int V) {
   }
   e.reset();  // wrong shape: free its memory before the new engine allocates
   Layout L(ext[0], ext[1], ext[2]);
-  const double need = (4.0 * V + 2.0) * (double)L.B() * 1.02;
+  const double need = ((4.0 * V + 3.0) * (double)L.B() + 4.0 * (double)embed_floats) * 1.02;
   size_t free_b = 0, total_b = 0;
   be::device_mem_info(&free_b, &total_b);
   if (trace_on())
@@ -305,7 +307,10 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
     const int dev = pick_device(device);
     std::lock_guard<std::mutex> lk(device_mutex(dev));
     be::set_device(dev);
-    std::unique_ptr<Engine> eng_owner = take_engine(dev, ext, V);  // on failure it is simply dropped
+    const bool embedded = ext[0] != dims[0] || ext[1] != dims[1] || ext[2] != dims[2];
+    // on failure the engine is simply dropped
+    std::unique_ptr<Engine> eng_owner =
+        take_engine(dev, ext, V, embedded ? (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2] : 0);
     Engine& eng = *eng_owner;
     eng.begin_call();
     // stacks are embedded into / cropped out of the padded volume by the transfers themselves
@@ -383,6 +388,15 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
 
 int mvn_set_pad_mode(const char* mode) {
   return guarded("mvn_set_pad_mode", [&] { g_pad_mode.store(parse_pad_mode(mode)); });
+}
+
+const char* mvn_get_pad_mode(void) {
+  switch (g_pad_mode.load()) {
+    case MVN_PAD_ZERO: return "zero";
+    case MVN_PAD_ZERO_EXACT: return "zero_exact";
+    case MVN_PAD_NONE: return "none";
+    default: return "";
+  }
 }
 
 // single convolution on the engine's kernels; shared by the three convolution entry points

@@ -16,7 +16,8 @@ from .abi import Workspace, c_float_p, c_int_p, fptr, iptr
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-PRODUCT_SO = os.path.join(LIB_DIR, "libmultiviewnative.so")
+# MVN_PRODUCT_SO: timing-probe builds of the same HIP library (`make probe`); never a fallback
+PRODUCT_SO = os.environ.get("MVN_PRODUCT_SO") or os.path.join(LIB_DIR, "libmultiviewnative.so")
 EMU_SO = os.environ.get("MVN_EMU_SO") or os.path.join(LIB_DIR, "libmvn_emu.so")  # override: sanitizer build
 
 REFERENCE_ABI_SYMBOLS = [
@@ -28,7 +29,7 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_get_pad_mode", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
@@ -69,6 +70,8 @@ class Binding:
         l.mvn_kernel_kind_name.restype = C.c_char_p
         l.mvn_kernel_kind_name.argtypes = [C.c_int]
         l.mvn_set_pad_mode.argtypes = [C.c_char_p]
+        l.mvn_get_pad_mode.restype = C.c_char_p
+        l.mvn_get_pad_mode.argtypes = []
         l.inplace_gpu_deconvolve.argtypes = [c_float_p, Workspace, C.c_int]
         l.inplace_gpu_deconvolve.restype = None
         for n in ("inplace_gpu_convolution", "convolution3DfftCUDAInPlace"):
@@ -156,19 +159,25 @@ class Binding:
         """'zero' | 'zero_exact' | 'none' | None (back to MVN_PAD_MODE / the default)."""
         self.check(self.l.mvn_set_pad_mode(mode.encode() if mode else None))
 
+    def get_pad_mode(self):
+        """The mode selected with set_pad_mode, None when the environment / default decides."""
+        return self.l.mvn_get_pad_mode().decode() or None
+
     # ---- reference ABI, numpy in / numpy out ----------------------------------------------
     def gpu_deconvolve(self, psi, holder, device=0, pad_mode="none"):
         """inplace_gpu_deconvolve on a copy of psi.  `pad_mode` defaults to the CPU path's cyclic
         policy, the one the oracle implements (the library's own default is 'zero', the reference
-        GPU entry's); pass pad_mode=False to leave the process-wide setting alone."""
+        GPU entry's); pass pad_mode=False to leave the process-wide setting alone.  The setting
+        found on entry is restored on exit (the switch is process-wide: not for concurrent callers)."""
         out = np.ascontiguousarray(psi, dtype=np.float32).copy()
+        before = self.get_pad_mode()
         if pad_mode is not False:
             self.set_pad_mode(pad_mode)
         try:
             self.l.inplace_gpu_deconvolve(fptr(out), holder.ws, device)
         finally:
             if pad_mode is not False:
-                self.set_pad_mode(None)
+                self.set_pad_mode(before)
         return out
 
     def gpu_deconvolve_inplace(self, psi, holder, device=0):

@@ -416,14 +416,18 @@ static fftw_plans* fftw_get_plans(int d0, int d1, int d2, int nthreads) {
       if (p->d0 == d0 && p->d1 == d1 && p->d2 == d2 && p->nthreads == nthreads) break;
     if (!p) {
       /* FFTW_MEASURE (= 0, inc/plan_store.h:117,122) overwrites the arrays while planning:
-       * plan on a scratch volume, execute with the new-array interface */
+       * plan on a scratch volume, execute with the new-array interface.  The arrays executed on
+       * are the callers' (numpy buffers of any alignment), so the plans carry FFTW_UNALIGNED
+       * (1 << 1): the new-array interface is only defined for arrays as aligned as the planned one
+       * otherwise. */
+      const unsigned flags = 0u /* FFTW_MEASURE */ | (1u << 1) /* FFTW_UNALIGNED */;
       const size_t nfl = (size_t)d0 * d1 * 2u * (size_t)(d2 / 2 + 1);
       float* scratch = (float*)calloc(nfl, sizeof(float));
       if (g_fftw.threads_ok) g_fftw.plan_with_nthreads(nthreads);
       p = (fftw_plans*)calloc(1, sizeof(fftw_plans));
       p->d0 = d0; p->d1 = d1; p->d2 = d2; p->nthreads = nthreads;
-      p->fwd = g_fftw.plan_r2c(d0, d1, d2, scratch, scratch, 0u);
-      p->bwd = g_fftw.plan_c2r(d0, d1, d2, scratch, scratch, 0u);
+      p->fwd = g_fftw.plan_r2c(d0, d1, d2, scratch, scratch, flags);
+      p->bwd = g_fftw.plan_c2r(d0, d1, d2, scratch, scratch, flags);
       free(scratch);
       p->next = g_fftw_plans;
       g_fftw_plans = p;

@@ -8,3 +8,5 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "asan: runs the host emulation of the kernels under AddressSanitizer + UBSan "
+                                       "(CPU only; builds lib/libmvn_emu_asan.so on first use)")

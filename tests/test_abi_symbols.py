@@ -37,12 +37,27 @@ def test_every_declared_symbol_is_exported(product):
         assert hasattr(product, name), name
 
 
+def dynamic_symbols(path):
+    """every DEFINED symbol of the dynamic table, whatever its type (T, W, V, u, B, D, ...)"""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return {l.split()[-1].split("@")[0]: l.split()[-2] for l in out.splitlines() if len(l.split()) >= 3}
+
+
 def test_only_the_abi_is_exported():
-    out = subprocess.check_output(["nm", "-D", "--defined-only", native.PRODUCT_SO]).decode()
-    syms = {l.split()[-1] for l in out.splitlines() if " T " in l}
-    allowed = set(native.REFERENCE_ABI_SYMBOLS) | set(native.ENGINE_ABI_SYMBOLS)
-    extra = {s for s in syms if s not in allowed and not s.startswith("_")}
+    # no kernel stubs (V), no weak libstdc++ instantiations (W), no HIP fat-binary bookkeeping (B/D):
+    # the linker version script csrc/mvn_exports.map keeps everything but the C-ABI local
+    syms = dynamic_symbols(native.PRODUCT_SO)
+    allowed = set(native.REFERENCE_ABI_SYMBOLS) | set(native.ENGINE_ABI_SYMBOLS) | {"MVN_1"}
+    extra = {s: t for s, t in syms.items() if s not in allowed}
     assert not extra, extra
+    assert all(syms[s] == "T" for s in allowed - {"MVN_1"}), syms
+
+
+def test_version_script_lists_exactly_the_headers():
+    txt = open(os.path.join(ROOT, "libmultiviewnative_amd", "csrc", "mvn_exports.map")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    listed = re.findall(r"^\s+(\w+);", txt[txt.index("global:"):txt.index("local:")], flags=re.M)
+    assert sorted(listed) == sorted(declared("multiviewnative.h") + declared("mvn_engine_api.h"))
 
 
 def test_no_cpu_entry_points_in_the_product(product):

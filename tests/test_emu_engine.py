@@ -649,10 +649,12 @@ def test_default_padding_policy_on_a_block(emu):
     emu.l.mvn_release_cached_engines()
 
 
-@pytest.mark.parametrize("mask", ["15", "4", "0"])
+@pytest.mark.parametrize("mask", ["15", "12", "0"])
 def test_wave_row_kernels_d2_512(emu, monkeypatch, mask):
     # d2 = 512: the last-axis passes in which a row never leaves its half-wave (mvn_wave_rows.hpp):
-    # every pass (mask 15), the product default (4: fused divide only), none (the tiled kernels)
+    # every pass (mask 15), the product default (12: fused divide + fused update / store), none (the
+    # tiled kernels).  The emulation reads the mask at every launch; the HIP backend once per process
+    # (tests/test_gpu_parity.py::test_wave_row_variants_in_a_child_process covers it there).
     monkeypatch.setenv("MVN_WAVE_ROWS_MASK", mask)
     shape = (4, 12, 512)  # 48 rows = 24 row pairs: ragged last sweep of the emulation's small grid
     assert emu.plan_describe(shape)["fx_rows"] == 1

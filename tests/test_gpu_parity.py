@@ -865,6 +865,66 @@ def test_full_size_512_six_views_vs_oracle(gpu, orc):
     assert np.abs(got - psi0).max() > 1e-2 * np.abs(psi0).max()  # the sweep did change psi
 
 
+def _record(name, rows):
+    """full-length parity figures for BASELINE.md section 3 (gpurun_out/ travels back from the GPU box)"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "full_length_parity_%s.json" % name), "w") as f:
+            json.dump(rows, f, indent=1)
+    except OSError:
+        pass
+    print(name, rows)
+
+
+def _full_length(gpu, orc, shape, V, kshape, checkpoints, seed):
+    """Resident engine vs oracle over BASELINE's full iteration count, compared at `checkpoints`
+    (cumulative sweeps): the oracle continues from its own previous result (N iterations == N x 1
+    iteration, tests/test_oracle_deconvolve.py), the engine from its own."""
+    from ref_fixtures import structured_views
+    views, k1, k2, w, psi0 = structured_views(shape, V, kshape, seed=seed)
+    eng = gpu.engine(shape, V)
+    for v in range(V):
+        eng.set_view(v, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    ref, done, rows = psi0, 0, []
+    n_ref = 64.0 ** 3  # the reference accepts sum(d^2) < 1 on its fixture volume; scaled per voxel of a 64^3 block
+    for upto in checkpoints:
+        eng.iterate(upto - done, 0.006, 1e-4)
+        got = eng.get_psi()
+        h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, upto - done)
+        ref = orc.cpu_deconvolve(ref, h, -1)
+        done = upto
+        mx, rms = rel_err(got, ref)
+        ssd = float(((got.astype(np.float64) - ref) ** 2).sum())
+        rows.append({"sweeps": upto, "max_rel": mx, "rms_rel": rms, "sum_sq_diff": ssd,
+                     "sum_sq_diff_per_64cubed": ssd * n_ref / got.size})
+        assert mx <= MAX_REL and rms <= RMS_REL, rows
+        # tests/test_gpu_deconvolve_impl.cu:200,260,323 (sum of squared differences < 1 after 2 / 5 / 10
+        # iterations), scaled to the volume
+        assert ssd * n_ref / got.size < 1, rows
+    eng.close()
+    assert np.abs(got - psi0).max() > 1e-2 * np.abs(psi0).max()
+    return rows
+
+
+def test_full_length_config2_512_six_views_ten_iterations_vs_oracle(gpu, orc):
+    # BASELINE.json configs[2] at FULL size AND full length: 512^3, 6 views, 31^3 PSFs, 10 sequential
+    # sweeps, compared after 1 / 5 / 10 (error growth over 60 Gauss-Seidel view updates); about a
+    # minute of oracle time on the box's cores
+    _record("config2", _full_length(gpu, orc, (512, 512, 512), 6, (31, 31, 31), (1, 5, 10), seed=7))
+
+
+def test_full_length_config4_kernels_six_views_twenty_iterations_vs_oracle(gpu, orc):
+    # BASELINE.json configs[4]'s kernels at its full length: a 16-plane slab of 320 x 1920 x 1920
+    # (1920-lines, 960-bin rows, split-window passes), 6 views, 20 sweeps, compared after 1 / 10 / 20
+    shape = (16, 1920, 1920)
+    info = gpu.plan_describe(shape)
+    assert info["fx_rows"] == 1 and info["fx_ax1"] == 1
+    _record("config4", _full_length(gpu, orc, shape, 6, (9, 31, 31), (1, 10, 20), seed=5))
+
+
 def test_config3_eight_views_simultaneous_512_vs_oracle(gpu, orc):
     # BASELINE.json configs[3] on ONE GPU: 512^3, 8 views, simultaneous (Jacobi) update -- what the 8
     # ranks of the sharded run compute together -- in 4 dim0 chunks (the overlapped form), one
@@ -1067,3 +1127,61 @@ def test_default_padding_policy_on_a_block(gpu, orc):
         orc.set_quotient_guard(False)
     mx, rms = rel_err(got, ref)
     assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms, ext)
+
+
+_WAVE_ROWS_CHILD = r"""
+import os, sys
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from libmultiviewnative_amd import native
+from libmultiviewnative_amd.abi import WorkspaceHolder
+from oracle import binding as orc
+from ref_fixtures import realistic_views
+gpu = native.lib()
+assert gpu.backend_name() == "hip-gfx950"
+for shape in [(6, 40, 512), (3, 7, 512)]:   # 240 rows: whole sweeps; 21 rows: ragged last pair
+    assert gpu.plan_describe(shape)["fx_rows"] == 1
+    x = np.random.default_rng(1).standard_normal(shape).astype(np.float32)
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = gpu.rfft3(x)
+    assert np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max(), "r2c"
+    back = gpu.irfft3(got, shape[2]) / np.float32(np.prod(shape))
+    assert np.abs(back - x).max() < 2e-5, "c2r"
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (3, 5, 7), seed=3)
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+        got = gpu.gpu_deconvolve(psi0, h)
+        ref = orc.cpu_deconvolve(psi0, h, 4)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), ("sequential", lam)
+        e = gpu.engine(shape, 2)
+        for v in range(2):
+            e.set_view(v, views[v], w[v], k1[v], k2[v])
+        e.set_psi(psi0)
+        for _ in range(2):
+            e.compute_delta(lam, 1e-4)
+            e.apply_delta()
+        got = e.get_psi()
+        e.close()
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 2)
+        ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), ("simultaneous", lam)
+print("wave-row child ok", os.environ.get("MVN_WAVE_ROWS_MASK"))
+"""
+
+
+@pytest.mark.parametrize("mask", ["15", "0"])
+def test_wave_row_variants_in_a_child_process(gpu, mask):
+    # the wave-row forms the default mask (12) leaves off -- plain r2c, plain c2r with the STORE /
+    # DIVIDE / UPDATE / DELTA epilogues -- and, with mask 0, the tiled kernels they replace, on the
+    # GPU: the HIP backend reads MVN_WAVE_ROWS_MASK once per process, hence the child.  Only the
+    # hardware can check what these kernels rely on (one wave's LDS instructions execute in order,
+    # no workgroup barrier between the phases of a row).
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVN_WAVE_ROWS_MASK=mask)
+    env.pop("MVN_NO_WAVE_ROWS", None)
+    r = subprocess.run([sys.executable, "-c", _WAVE_ROWS_CHILD, root], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "wave-row child ok " + mask in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

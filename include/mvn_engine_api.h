@@ -23,6 +23,20 @@ MVN_API const char* mvn_backend_name(void);
 /* inplace_gpu_deconvolve keeps one resident engine per device between calls (same shape and view
  * count are re-used without re-allocating; MVN_ENGINE_CACHE=0 disables it).  This frees them. */
 MVN_API int mvn_release_cached_engines(void);
+
+/* Block-after-block callers (Fiji deconvolves a large volume as a sequence of blocks): the
+ * asynchronous form of inplace_gpu_deconvolve.  Submit starts the call on a worker thread and
+ * returns a ticket; wait blocks until that call is complete (psi written) and returns its status.
+ * Submits to one device alternate between two resident engines, so the stacks of block k+1 cross
+ * PCIe while block k iterates -- what the reference's interleaved driver
+ * (inplace_gpu_deconvolve_iteration_interleaved, src/gpu_deconvolve_methods.cuh:82-326, "not
+ * supported yet" there) was meant to do inside one call.  The workspace struct, its view_data array
+ * and the int[3] dims are copied at submit; psi and every stack / kernel buffer they point to must
+ * stay valid and untouched until the matching wait returns.  The padding policy is the one in
+ * force at submit.  Results are those of inplace_gpu_deconvolve, bit for bit.  Every ticket must
+ * be waited for exactly once; inplace_gpu_deconvolve == submit + wait on the first engine. */
+MVN_API int mvn_deconvolve_submit(imageType* psi, struct workspace input, int device, long long* ticket);
+MVN_API int mvn_deconvolve_wait(long long ticket);
 /* Padding policy of inplace_gpu_deconvolve for the calls that follow (process-wide): "zero"
  * (default: the reference GPU entry's zero_padd with FFT-friendly padded extents), "zero_exact"
  * (exactly image + kernel - 1), "none" (the reference CPU path's cyclic no_padd); NULL or ""

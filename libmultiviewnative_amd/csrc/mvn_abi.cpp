@@ -99,8 +99,8 @@ static std::unique_ptr<Engine> pop_cached_engine(int dev) {
 // shape is re-used as it is (its memory is what the check would ask for), and a stale one of another
 // shape is freed BEFORE the free memory is read -- so that "does not fit" is said here, before any
 // work is queued, not by a failing hipMalloc on the staging thread.
-static std::unique_ptr<Engine> take_engine(int dev, const shape_t& ext, int V, size_t embed_floats) {
-  std::unique_ptr<Engine> e = pop_cached_engine(dev);
+static std::unique_ptr<Engine> take_engine(int key, int dev, const shape_t& ext, int V, size_t embed_floats) {
+  std::unique_ptr<Engine> e = pop_cached_engine(key);  // key = device + lane * kLaneStride
   if (e && engine_cache_enabled()) {
     const Layout& L = e->layout();
     if (L.d0 == ext[0] && L.d1 == ext[1] && L.d2 == ext[2] && e->num_views() == V) return e;
@@ -268,17 +268,32 @@ int selectDeviceWithHighestComputeCapability(void) {
 // ---------------------------------------------------------------------------------------------
 // reference hot path
 // ---------------------------------------------------------------------------------------------
-void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) {
-  guarded("inplace_gpu_deconvolve", [&] {
-    if (!psi || !input.data_) throw std::invalid_argument("null psi or workspace");
+// Two LANES per device: a lane is what used to be "the device" for the blocking call -- its own
+// mutex and its own cached resident engine (keys dev and dev + kLaneStride of device_mutex() /
+// engine_cache()).  inplace_gpu_deconvolve and every other blocking entry point run on lane 0;
+// mvn_deconvolve_submit alternates between the two, so that block k+1's stacks cross PCIe into the
+// second engine while block k iterates in the first (the intent of
+// inplace_gpu_deconvolve_iteration_interleaved, src/gpu_deconvolve_methods.cuh:82-326).  Uploads of
+// the two lanes take turns (upload_mutex): one block at full PCIe rate starts iterating sooner than
+// two at half rate each.
+static const int kLaneStride = 1024;
+static std::mutex& upload_mutex(int dev) { return device_mutex(2 * kLaneStride + dev); }
+
+static void check_workspace(const imageType* psi, const workspace& input) {
+  if (!psi || !input.data_) throw std::invalid_argument("null psi or workspace");
+  for (int v = 0; v < input.num_views_; ++v) {  // before anything is dereferenced
+    const view_data& d = input.data_[v];
+    if (!d.image_ || !d.kernel1_ || !d.kernel2_ || !d.weights_ || !d.image_dims_ ||
+        !d.kernel1_dims_ || !d.kernel2_dims_)
+      throw std::invalid_argument("view " + std::to_string(v) + " has null members");
+  }
+}
+
+static void deconvolve_call(imageType* psi, const workspace& input, int device, int lane, int pad_mode) {
+  {
+    check_workspace(psi, input);
     const int V = input.num_views_;
     if (V == 0 || input.num_iterations_ <= 0) return;  // 0 iterations returns psi unchanged
-    for (int v = 0; v < V; ++v) {  // before anything is dereferenced
-      const view_data& d = input.data_[v];
-      if (!d.image_ || !d.kernel1_ || !d.kernel2_ || !d.weights_ || !d.image_dims_ ||
-          !d.kernel1_dims_ || !d.kernel2_dims_)
-        throw std::invalid_argument("view " + std::to_string(v) + " has null members");
-    }
     const shape_t dims = to_shape(input.data_[0].image_dims_);
     for (int v = 0; v < V; ++v) {
       const view_data& d = input.data_[v];
@@ -289,8 +304,7 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
     }
     for (int d = 0; d < 3; ++d)
       if (dims[d] < 1) throw std::invalid_argument("image extents must be >= 1");
-    const int pad_mode = current_pad_mode();  // see the block comment above good_extent()
-    shape_t ext = dims;
+    shape_t ext = dims;  // padding policy: see the block comment above good_extent()
     int off[3] = {0, 0, 0};
     if (pad_mode != MVN_PAD_NONE) {
       for (int d = 0; d < 3; ++d) {
@@ -305,12 +319,13 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
       }
     }
     const int dev = pick_device(device);
-    std::lock_guard<std::mutex> lk(device_mutex(dev));
+    const int key = dev + lane * kLaneStride;
+    std::lock_guard<std::mutex> lk(device_mutex(key));
     be::set_device(dev);
     const bool embedded = ext[0] != dims[0] || ext[1] != dims[1] || ext[2] != dims[2];
     // on failure the engine is simply dropped
     std::unique_ptr<Engine> eng_owner =
-        take_engine(dev, ext, V, embedded ? (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2] : 0);
+        take_engine(key, dev, ext, V, embedded ? (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2] : 0);
     Engine& eng = *eng_owner;
     eng.begin_call();
     // stacks are embedded into / cropped out of the padded volume by the transfers themselves
@@ -333,7 +348,7 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
       eng.iterate(input.num_iterations_, input.lambda_, input.minValue_);
       eng.sync();
       eng.get_psi(psi);
-      give_back_engine(dev, std::move(eng_owner));
+      give_back_engine(key, std::move(eng_owner));
       return;
     }
     // stacks arrive view by view from a second host thread while the first iteration already
@@ -348,11 +363,13 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
     };
     eng.reserve_views();
     lap("allocate view buffers");
+    std::unique_lock<std::mutex> pcie(upload_mutex(dev));  // handed to the uploader thread's scope below
     eng.set_psi(psi);
     lap("upload psi");
     std::exception_ptr up_err;
     std::thread uploader([&] {
       try {
+        be::set_device(dev);
         auto u0 = std::chrono::steady_clock::now();
         for (int v = 0; v < V; ++v) {
           const view_data& d = input.data_[v];
@@ -375,6 +392,7 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
     }
     lap("enqueue iterations");
     uploader.join();
+    pcie.unlock();  // the other lane's block may start crossing PCIe while this one iterates
     lap("join uploader");
     if (up_err) std::rethrow_exception(up_err);
     if (main_err) std::rethrow_exception(main_err);
@@ -382,8 +400,96 @@ void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) 
     lap("wait for the device");
     eng.get_psi(psi);
     lap("download psi");
-    give_back_engine(dev, std::move(eng_owner));
+    give_back_engine(key, std::move(eng_owner));
+  }
+}
+
+void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device) {
+  guarded("inplace_gpu_deconvolve", [&] { deconvolve_call(psi, input, device, 0, current_pad_mode()); });
+}
+
+// ---- asynchronous pair: mvn_deconvolve_submit / mvn_deconvolve_wait ---------------------------
+extern "C++" {
+namespace {
+struct DeconvJob {
+  std::thread worker;
+  int rc = 0;
+  std::string error;
+  std::vector<view_data> views;  // the caller's view_data array and dims, copied at submit
+  std::vector<int> dims;
+  workspace ws;
+};
+std::mutex& jobs_mutex() {
+  static std::mutex* m = new std::mutex();
+  return *m;
+}
+std::map<long long, std::unique_ptr<DeconvJob>>& jobs() {  // leaked on purpose: no joinable thread is destroyed at exit
+  static auto* j = new std::map<long long, std::unique_ptr<DeconvJob>>();
+  return *j;
+}
+}  // namespace
+}  // extern "C++"
+
+int mvn_deconvolve_submit(imageType* psi, struct workspace input, int device, long long* ticket) {
+  return guarded("mvn_deconvolve_submit", [&] {
+    if (!ticket) throw std::invalid_argument("null ticket");
+    *ticket = 0;
+    check_workspace(psi, input);
+    const int V = input.num_views_;
+    std::unique_ptr<DeconvJob> job(new DeconvJob());
+    job->views.assign(input.data_, input.data_ + V);
+    job->dims.resize((size_t)V * 12);
+    for (int v = 0; v < V; ++v) {  // the four int[3] of every view move into the job
+      view_data& d = job->views[v];
+      int* base = job->dims.data() + (size_t)v * 12;
+      int** members[4] = {&d.image_dims_, &d.kernel1_dims_, &d.kernel2_dims_, &d.weights_dims_};
+      for (int m = 0; m < 4; ++m) {
+        if (!*members[m]) continue;  // weights_dims_ may be null
+        std::memcpy(base + 3 * m, *members[m], 3 * sizeof(int));
+        *members[m] = base + 3 * m;
+      }
+    }
+    job->ws = input;
+    job->ws.data_ = job->views.data();
+    const int dev = pick_device(device);
+    const int pad_mode = current_pad_mode();  // the policy in force at submit time
+    static std::atomic<long long> next_ticket{1};
+    const long long id = next_ticket.fetch_add(1);
+    static std::mutex lane_mu;
+    static std::map<int, int> lane_of;  // submits per device so far -> lanes alternate
+    int lane;
+    {
+      std::lock_guard<std::mutex> lk(lane_mu);
+      lane = lane_of[dev]++ & 1;
+    }
+    DeconvJob* j = job.get();
+    {
+      std::lock_guard<std::mutex> lk(jobs_mutex());
+      jobs()[id] = std::move(job);
+    }
+    j->worker = std::thread([j, psi, dev, lane, pad_mode] {
+      j->rc = guarded("mvn_deconvolve_submit (worker)", [&] { deconvolve_call(psi, j->ws, dev, lane, pad_mode); });
+      if (j->rc < 0) j->error = g_last_error;  // the worker's thread-local message travels with the job
+    });
+    *ticket = id;
   });
+}
+
+int mvn_deconvolve_wait(long long ticket) {
+  std::unique_ptr<DeconvJob> job;
+  const int rc = guarded("mvn_deconvolve_wait", [&] {
+    {
+      std::lock_guard<std::mutex> lk(jobs_mutex());
+      auto it = jobs().find(ticket);
+      if (it == jobs().end()) throw std::invalid_argument("unknown or already awaited ticket");
+      job = std::move(it->second);
+      jobs().erase(it);
+    }
+    if (job->worker.joinable()) job->worker.join();
+  });
+  if (rc < 0) return rc;
+  if (job->rc < 0) g_last_error = job->error;
+  return job->rc;
 }
 
 int mvn_set_pad_mode(const char* mode) {

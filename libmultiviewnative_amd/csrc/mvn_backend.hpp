@@ -42,6 +42,12 @@ void d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t wid
 void dzero(void* d, size_t bytes, stream_t s);
 
 stream_t stream_create();
+// a stream of the device's highest priority: it gets hardware queues of its own, so that host->device
+// copies never sit behind another engine's kernels in a SHARED hardware queue (ROCm multiplexes a
+// process's normal-priority streams onto 4 queues: with two resident engines x (compute, Nyquist,
+// upload) streams the upload stream of one aliased the compute stream of the other and block k+1's
+// upload ran at 31 instead of 56 GB/s under block k's iterations -- profiles/r03_pipeline.md)
+stream_t stream_create_upload();
 void stream_destroy(stream_t s);
 void stream_sync(stream_t s);
 

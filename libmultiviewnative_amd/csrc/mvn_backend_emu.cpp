@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "mvn_backend.hpp"
@@ -47,7 +48,10 @@ int device_count() {
   return n > 0 ? n : 1;
 }
 static thread_local int t_device = 0;
-void set_device(int d) { t_device = d; }
+void set_device(int d) {  // as strict as hipSetDevice: a lane key or a stale id must not pass here either
+  if (d < 0 || d >= device_count()) throw std::runtime_error("emu: invalid device ordinal " + std::to_string(d));
+  t_device = d;
+}
 int get_device() { return t_device; }
 void device_name(int, char* name256) {
   std::memset(name256, 0, 256);
@@ -115,6 +119,7 @@ void d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t wid
 void dzero(void* d, size_t bytes, stream_t) { std::memset(d, 0, bytes); }
 
 stream_t stream_create() { return (stream_t)1; }
+stream_t stream_create_upload() { return (stream_t)1; }
 void stream_destroy(stream_t) {}
 void stream_sync(stream_t) {}
 void stream_wait_event(stream_t, event_t) {}
@@ -144,7 +149,7 @@ void graph_destroy(graph_exec_t) {}
 static bool emu_wave_rows(const RowsParams& p, int kind_bit) {
   const char* e = std::getenv("MVN_NO_WAVE_ROWS");
   const char* m = std::getenv("MVN_WAVE_ROWS_MASK");
-  const int mask = m && *m ? std::atoi(m) : 15;
+  const int mask = m && *m ? std::atoi(m) : 31;
   return !(e && *e && std::strcmp(e, "0") != 0) && (mask & kind_bit) && p.fixed && p.h == WrCfg::H &&
          p.C == WrCfg::H;
 }
@@ -361,7 +366,7 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t ld
 
 void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
-  if (emu_wave_rows(p, 2)) return emu_wave_rows_mode<MVN_WR_C2R>(p);
+  if (emu_wave_rows(p, p.epi.mode == MVN_EPI_DELTA ? 16 : 2)) return emu_wave_rows_mode<MVN_WR_C2R>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, false)) throw std::invalid_argument("mvn: no fixed kernel");
     return;

@@ -784,7 +784,7 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
 void Engine::reserve_views() {
   be::set_device(device_);
   for (size_t v = 0; v < views_.size(); ++v) alloc_view(views_[v]);
-  if (!upload_stream_) upload_stream_ = be::stream_create();
+  if (!upload_stream_) upload_stream_ = be::stream_create_upload();
   staged_ev_.resize(views_.size(), nullptr);
   for (size_t v = 0; v < views_.size(); ++v)
     if (!staged_ev_[v]) staged_ev_[v] = be::event_create_sync();

@@ -299,6 +299,13 @@ stream_t stream_create() {
   HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   return (stream_t)s;
 }
+stream_t stream_create_upload() {
+  int least = 0, greatest = 0;
+  HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  hipStream_t s;
+  HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+  return (stream_t)s;
+}
 void stream_destroy(stream_t s) {
   if (s) (void)hipStreamDestroy(hs(s));
 }
@@ -467,7 +474,10 @@ static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads
 
 // wave-row kernels (d2 = 512): workgroups sweep over the row pairs, the grid is what the device
 // holds at once.  MVN_WAVE_ROWS_MASK selects the passes that use them (1 plain r2c, 2 plain c2r,
-// 4 fused divide, 8 fused update / store); MVN_NO_WAVE_ROWS=1 = mask 0.  Default 12: measured at
+// 4 fused divide, 8 fused update / store, 16 c2r with the DELTA epilogue of the sharded step);
+// MVN_NO_WAVE_ROWS=1 = mask 0.  Default 28 (round 3: the DELTA form 0.498 vs 0.512 ms tiled, 16 workgroups
+// per slot; 8 / 32 per slot 0.507 / 0.504 -- a pass with three read streams is bound by the read path,
+// profiles/r03_mem_counters.md).  Bits 4 and 8: measured at
 // 512^3 on MI355X (tools/ab_env.sh, same box) the fused divide gains 12 % over the tiled kernel
 // (0.376 -> 0.330 ms) and, with the twiddle tables transposed in the LDS, the fused update 2 %
 // (0.485 -> 0.475 ms); the plain r2c / c2r passes, which the tiled kernels already run at the
@@ -479,7 +489,7 @@ static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
   }();
   static const int mask = [] {
     const char* e = std::getenv("MVN_WAVE_ROWS_MASK");
-    return e && *e ? std::atoi(e) : 12;
+    return e && *e ? std::atoi(e) : 28;
   }();
   return !off && (mask & kind_bit) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
 }
@@ -570,7 +580,7 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
   if (p.fixed) {
     check_aligned16(p.in_cplx, "input");
     check_aligned16(p.out_real, "output");
-    if (wave_rows_enabled(p, 2)) {
+    if (wave_rows_enabled(p, p.epi.mode == MVN_EPI_DELTA ? 16 : 2)) {
       switch (p.epi.mode) {
         case MVN_EPI_DIVIDE: return launch_wave_rows(kw_rows<MVN_WR_C2R, MVN_EPI_DIVIDE>, p, s);
         case MVN_EPI_UPDATE: return launch_wave_rows(kw_rows<MVN_WR_C2R, MVN_EPI_UPDATE>, p, s);
@@ -708,7 +718,7 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
 
 static unsigned flat_grid(size_t n, int block) {
   size_t g = (n + (size_t)block - 1) / (size_t)block;
-  const size_t cap = 256 * 8;  // ~8 blocks per CU, grid-stride the rest
+  const size_t cap = (size_t)device_cu_count() * 8;  // ~8 blocks per CU of THIS device, grid-stride the rest
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (unsigned)g;

@@ -29,7 +29,7 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_get_pad_mode", "mvn_release_cached_engines", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_get_pad_mode", "mvn_release_cached_engines", "mvn_deconvolve_submit", "mvn_deconvolve_wait", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
@@ -74,6 +74,8 @@ class Binding:
         l.mvn_get_pad_mode.argtypes = []
         l.inplace_gpu_deconvolve.argtypes = [c_float_p, Workspace, C.c_int]
         l.inplace_gpu_deconvolve.restype = None
+        l.mvn_deconvolve_submit.argtypes = [c_float_p, Workspace, C.c_int, C.POINTER(C.c_longlong)]
+        l.mvn_deconvolve_wait.argtypes = [C.c_longlong]
         for n in ("inplace_gpu_convolution", "convolution3DfftCUDAInPlace"):
             getattr(l, n).argtypes = [c_float_p, c_int_p, c_float_p, c_int_p, C.c_int]
             getattr(l, n).restype = None
@@ -179,6 +181,19 @@ class Binding:
             if pad_mode is not False:
                 self.set_pad_mode(before)
         return out
+
+    def deconvolve_submit(self, psi, holder, device=0):
+        """mvn_deconvolve_submit: starts inplace_gpu_deconvolve on `psi` (C-contiguous float32, updated in
+        place by the time deconvolve_wait returns) and returns the ticket.  `psi` and `holder` must be
+        kept alive and untouched until then."""
+        if not (psi.flags["C_CONTIGUOUS"] and psi.dtype == np.float32):
+            raise ValueError("psi must be a C-contiguous float32 array")
+        t = C.c_longlong(0)
+        self.check(self.l.mvn_deconvolve_submit(fptr(psi), holder.ws, device, C.byref(t)))
+        return t.value
+
+    def deconvolve_wait(self, ticket):
+        self.check(self.l.mvn_deconvolve_wait(ticket))
 
     def gpu_deconvolve_inplace(self, psi, holder, device=0):
         """The ABI call exactly as a host program makes it: `psi` (C-contiguous float32) is updated

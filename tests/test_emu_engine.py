@@ -649,10 +649,10 @@ def test_default_padding_policy_on_a_block(emu):
     emu.l.mvn_release_cached_engines()
 
 
-@pytest.mark.parametrize("mask", ["15", "12", "0"])
+@pytest.mark.parametrize("mask", ["31", "28", "0"])
 def test_wave_row_kernels_d2_512(emu, monkeypatch, mask):
     # d2 = 512: the last-axis passes in which a row never leaves its half-wave (mvn_wave_rows.hpp):
-    # every pass (mask 15), the product default (12: fused divide + fused update / store), none (the
+    # every pass (mask 31), the product default (28: fused divide, fused update / store, c2r + DELTA), none (the
     # tiled kernels).  The emulation reads the mask at every launch; the HIP backend once per process
     # (tests/test_gpu_parity.py::test_wave_row_variants_in_a_child_process covers it there).
     monkeypatch.setenv("MVN_WAVE_ROWS_MASK", mask)
@@ -713,3 +713,55 @@ def test_long_rows_small_tile_walking_kernels(emu, shape):
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
     ref = orc.cpu_deconvolve_simultaneous(psi0, h, 4)
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def _blocks(shape, n, V, kshape, its):
+    out = []
+    for b in range(n):
+        _, views, k1, k2, w, psi0 = realistic_views(shape, V, kshape, seed=20 + b)
+        out.append((WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, its), psi0))
+    return out
+
+
+def test_submit_wait_pipeline_equals_blocking_calls(emu, capfd):
+    # mvn_deconvolve_submit / mvn_deconvolve_wait: three blocks in flight on the two engine lanes of a
+    # device give, bit for bit, what three blocking inplace_gpu_deconvolve calls give (both policies);
+    # tickets are single-use; a failing block reports through its own wait and leaves its psi alone
+    shape = (12, 20, 16)
+    blocks = _blocks(shape, 3, 2, (3, 5, 3), 3)
+    for mode in ("none", "zero"):
+        emu.set_pad_mode(mode)
+        try:
+            want = [emu.gpu_deconvolve(psi0, h, pad_mode=False) for h, psi0 in blocks]
+            psis = [np.ascontiguousarray(psi0.copy()) for _, psi0 in blocks]
+            tickets = [emu.deconvolve_submit(psi, h) for psi, (h, _) in zip(psis, blocks)]
+            assert len(set(tickets)) == 3 and all(t > 0 for t in tickets)
+            for t in reversed(tickets):  # any order
+                emu.deconvolve_wait(t)
+            for got, ref in zip(psis, want):
+                assert np.array_equal(got, ref)
+        finally:
+            emu.set_pad_mode(None)
+    with pytest.raises(native.MvnError):
+        emu.deconvolve_wait(tickets[0])  # already awaited
+    with pytest.raises(native.MvnError):
+        emu.deconvolve_wait(12345678)
+    # a block whose views disagree in shape fails in ITS wait; the neighbours are unaffected
+    h_ok, psi_ok = blocks[0]
+    _, views, k1, k2, w, _ = realistic_views(shape, 2, (3, 5, 3), seed=31)
+    views[1] = np.ascontiguousarray(views[1][:, :10, :])
+    w[1] = np.ascontiguousarray(w[1][:, :10, :])
+    bad = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    emu.set_pad_mode("none")
+    try:
+        a, b = psi_ok.copy(), psi_ok.copy()
+        ta = emu.deconvolve_submit(a, h_ok)
+        tb = emu.deconvolve_submit(b, bad)
+        emu.deconvolve_wait(ta)
+        with pytest.raises(native.MvnError, match="share image_dims_"):
+            emu.deconvolve_wait(tb)
+        assert np.array_equal(b, psi_ok) and np.array_equal(a, emu.gpu_deconvolve(psi_ok, h_ok, pad_mode=False))
+    finally:
+        emu.set_pad_mode(None)
+    capfd.readouterr()
+    emu.l.mvn_release_cached_engines()

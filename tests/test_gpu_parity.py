@@ -1140,7 +1140,7 @@ from oracle import binding as orc
 from ref_fixtures import realistic_views
 gpu = native.lib()
 assert gpu.backend_name() == "hip-gfx950"
-for shape in [(6, 40, 512), (3, 7, 512)]:   # 240 rows: whole sweeps; 21 rows: ragged last pair
+for shape in [(6, 40, 512), (3, 16, 512)]:   # 240 / 48 rows (the fixed last-axis kernels take multiples of 16)
     assert gpu.plan_describe(shape)["fx_rows"] == 1
     x = np.random.default_rng(1).standard_normal(shape).astype(np.float32)
     ref = np.fft.rfftn(x.astype(np.float64))
@@ -1170,10 +1170,10 @@ print("wave-row child ok", os.environ.get("MVN_WAVE_ROWS_MASK"))
 """
 
 
-@pytest.mark.parametrize("mask", ["15", "0"])
+@pytest.mark.parametrize("mask", ["31", "0"])
 def test_wave_row_variants_in_a_child_process(gpu, mask):
-    # the wave-row forms the default mask (12) leaves off -- plain r2c, plain c2r with the STORE /
-    # DIVIDE / UPDATE / DELTA epilogues -- and, with mask 0, the tiled kernels they replace, on the
+    # the wave-row forms the default mask (28) leaves off -- plain r2c, plain c2r with the STORE /
+    # DIVIDE / UPDATE epilogues -- and, with mask 0, the tiled kernels they replace, on the
     # GPU: the HIP backend reads MVN_WAVE_ROWS_MASK once per process, hence the child.  Only the
     # hardware can check what these kernels rely on (one wave's LDS instructions execute in order,
     # no workgroup barrier between the phases of a row).
@@ -1185,3 +1185,29 @@ def test_wave_row_variants_in_a_child_process(gpu, mask):
     r = subprocess.run([sys.executable, "-c", _WAVE_ROWS_CHILD, root], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and "wave-row child ok " + mask in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_submit_wait_pipelines_three_blocks_bit_for_bit(gpu):
+    # SURVEY.md 8f row 3, second half: block k+1's stacks upload into the device's second resident
+    # engine while block k iterates.  Three 128^3 blocks (6 views, 15^3 PSFs, 5 iterations) through
+    # mvn_deconvolve_submit / mvn_deconvolve_wait == three blocking inplace_gpu_deconvolve calls, bit
+    # for bit, under the default (zero-padding) policy and under the cyclic one
+    shape, V = (128, 128, 128), 6
+    blocks = []
+    for b in range(3):
+        _, views, k1, k2, w, psi0 = realistic_views(shape, V, (15, 15, 15), seed=40 + b)
+        blocks.append((WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 5), psi0))
+    before = gpu.get_pad_mode()
+    try:
+        for mode in ("zero", "none"):
+            gpu.set_pad_mode(mode)
+            want = [gpu.gpu_deconvolve(psi0, h, pad_mode=False) for h, psi0 in blocks]
+            psis = [np.ascontiguousarray(psi0.copy()) for _, psi0 in blocks]
+            tickets = [gpu.deconvolve_submit(psi, h) for psi, (h, _) in zip(psis, blocks)]
+            for t in tickets:
+                gpu.deconvolve_wait(t)
+            for got, ref in zip(psis, want):
+                assert np.isfinite(got).all() and np.array_equal(got, ref)
+    finally:
+        gpu.set_pad_mode(before)
+        gpu.check(gpu.l.mvn_release_cached_engines())

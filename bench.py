@@ -83,7 +83,7 @@ def start_value():
     return 35.0  # the views are uniform in [10, 60)
 
 
-def kernel_bytes(kind, d0, d1, d2):
+def kernel_bytes(kind, d0, d1, d2, psf_planes=31):
     """Algorithmic HBM bytes of ONE launch of each kernel kind."""
     vol = 4.0 * d0 * d1 * d2            # dense real volume == main half-spectrum array
     nyq = 8.0 * d0 * d1 if d2 % 2 == 0 else 0.0
@@ -98,6 +98,8 @@ def kernel_bytes(kind, d0, d1, d2):
         "axis1_fwd": 2 * vol,
         "axis1_inv": 2 * vol,
         "axis0_fused": 3 * vol,         # read data, read PSF spectrum, write data
+        # direct dim0 leg: read data, read the PSF's planes after the dim1/dim2 transforms, write data
+        "axis0_direct": (2.0 + float(psf_planes) / d0) * vol,
         "axis0_fwd": 2 * vol,
         "axis0_inv": 2 * vol,
         "nyquist": 2 * nyq,
@@ -362,11 +364,12 @@ def run_rank(args, world_env):
         vol = 4.0 * d0 * d1 * d2
         # dominant kernel by total time inside the timed region
         roofline = None
-        prof = {k: v for k, v in prof.items() if v[1] and kernel_bytes(k, d0, d1, d2)[0] > 0}
+        KB = lambda k: kernel_bytes(k, d0, d1, d2, min(psf_edge, d0))
+        prof = {k: v for k, v in prof.items() if v[1] and KB(k)[0] > 0}
         if prof:
             kind = max(prof, key=lambda k: prof[k][0])
             tot_ms, n = prof[kind]
-            kb, B = kernel_bytes(kind, d0, d1, d2)
+            kb, B = KB(kind)
             avg_ms = tot_ms / max(n, 1)
             achieved = kb / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": kind, "achieved": round(achieved, 1),
@@ -374,7 +377,7 @@ def run_rank(args, world_env):
                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                         "bytes_per_launch": kb,
                         "per_kernel": {k: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1],
-                                           "GBps": round(kernel_bytes(k, d0, d1, d2)[0] / (v[0] / v[1] * 1e-3) / 1e9, 1)}
+                                           "GBps": round(KB(k)[0] / (v[0] / v[1] * 1e-3) / 1e9, 1)}
                                        for k, v in prof.items()}}
             traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(traffic_file) and shape == (512, 512, 512):  # PMC passes were taken at 512^3
@@ -418,10 +421,15 @@ def run_rank(args, world_env):
             "roofline": roofline,
         }
         if driver is None:
-            # what the 8-pass pipeline actually moves: 22 volumes per (view, iteration), DESIGN.md section 4
-            actual = 22.0 * vol * V / (ms_per_step * 1e-3) / 1e9
-            out["whole_step_GBps_actual_22vol"] = round(actual, 1)
+            # what the 8-pass pipeline actually moves per (view, iteration), DESIGN.md section 4: 22 volumes
+            # with the fused FFT dim0 pass, 20 + 2 K / d0 with the direct dim0 leg (K PSF planes)
+            direct = "axis0_direct" in prof
+            vols = 20.0 + 2.0 * min(psf_edge, d0) / d0 if direct else 22.0
+            actual = vols * vol * V / (ms_per_step * 1e-3) / 1e9
+            out["whole_step_volumes_moved_per_view_iteration"] = round(vols, 3)
+            out["whole_step_GBps_actual"] = round(actual, 1)
             out["whole_step_actual_frac_of_8TBps"] = round(actual / HBM_PEAK_GBS, 4)
+            out["dim0_leg"] = "direct (%d PSF planes)" % min(psf_edge, d0) if direct else "fused FFT pass"
         # The N > 1 lines time the simultaneous (Jacobi) loop, this line's `value` the reference-order
         # sequential sweep: a scaling series must be read against the SAME loop on one rank, so the
         # N = 1 line carries that rate too (same engine, same stacks, same step count).

@@ -11,6 +11,7 @@
 #include <cstddef>
 
 #include "mvn_pass_bodies.hpp"
+#include "mvn_dim0_direct.hpp"
 
 namespace mvn {
 namespace be {
@@ -84,6 +85,10 @@ void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int nthreads, size_t 
 long split_launch_count();
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
                     size_t lds_bytes, stream_t s);
+
+// the dim0 leg of a convolution as a direct cyclic convolution with the PSF's few planes
+// (mvn_dim0_direct.hpp); p.k must satisfy mvn_dim0_direct_possible(p.k, p.d0)
+void launch_dim0_direct(const Dim0DirectParams& p, stream_t s);
 
 // target[(z-kz/2 mod D0, y-ky/2 mod D1, x-kx/2 mod D2)] = kernel[z][y][x] * scale
 // (device-side wrapped_insert_at_point, inc/padd_utils.h:11-40; the reference's GPU twin is

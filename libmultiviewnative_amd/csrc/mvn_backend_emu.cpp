@@ -405,6 +405,22 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t 
   }
 }
 
+void launch_dim0_direct(const Dim0DirectParams& p, stream_t) {
+  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out)
+    throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
+  switch (mvn_dim0_taps_template(p.k)) {
+#define X(K)                                                                        \
+  case K: {                                                                         \
+    _Pragma("omp parallel for schedule(static)")                                    \
+    for (long b = 0; b < p.plane; ++b)                                              \
+      mvn_dim0_direct_column<K, MVN_D0_PF>(p, b, p.stagger > 0 ? (int)(((b / 256) * p.stagger) % p.d0) : 0); \
+  } break;
+    MVN_D0_TAP_COUNTS(X)
+#undef X
+    default: throw std::invalid_argument("mvn: no direct dim0 kernel for this tap count");
+  }
+}
+
 void launch_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
                         int D1, int D2, long pitch, float scale, stream_t) {
   const long total = (long)k0 * k1 * k2;

@@ -1,0 +1,130 @@
+// mvn_dim0_direct.hpp -- the dim0 leg of a convolution as a DIRECT cyclic convolution (round 3).
+//
+// The reference convolves by 3-D FFT x PSF spectrum x inverse 3-D FFT (inc/gpu_convolve.cuh:113-142,
+// inc/cpu_convolve.h:217-291).  A PSF has K = kernel_dims[0] planes along dim0 (31 in BASELINE.json)
+// against d0 = 512 of the volume.  In the spectral domain of dims 1 and 2 - where the volume is after
+// the forward last-axis and dim1 passes - the 3-D cyclic convolution is, for every bin b of the
+// (d1, C) plane, a 1-D cyclic convolution along dim0 with the K values the 2-D transformed PSF has
+// there:
+//
+//     out[z][b] = sum_{j=0}^{K-1} tap[j][b] * in[(z + h - j) mod d0][b],      h = K / 2
+//
+// (tap j = PSF plane j, whose voxel h sits on the origin: inc/padd_utils.h:11-40).  One pass over the
+// volume, 2 K packed fused multiply-adds per bin, instead of forward dim0 FFT x PSF x inverse dim0
+// FFT - and, what counts on MI355X (profiles/r03_mem_counters.md: a pass costs 0.16 ms per READ
+// volume at 512^3, its writes ride along), it reads the volume plus K / d0 of a volume of taps (6 %)
+// where the fused FFT pass reads the volume plus a whole PSF spectrum: 0.20 - 0.22 ms instead of
+// 0.32 ms at K = 31 (tools/dim0_direct_probe.hip), and the PSF costs 2 K / d0 volumes of HBM per
+// view instead of 2.
+//
+// A work item owns ONE bin and walks along dim0 with its K taps and the K + PF most recent / next
+// input values in registers (PF planes are requested ahead of their first use).  The walk is
+// unrolled K + PF times so that every register index is a compile-time constant:
+//   x_j = in[z + h - j] (j = -PF .. K-1) sits in slot (j + PF - u) mod (K + PF) at unrolled step u.
+#pragma once
+
+#include "mvn_fft_core.hpp"
+
+struct Dim0DirectParams {
+  const cfloat* in;    // [d0][plane]
+  cfloat* out;         // [d0][plane]; must not alias `in`
+  const cfloat* taps;  // [kd][plane]: tap j lives in plane (j - h + kd) % kd (the PSF scattered cyclically
+                       // into kd >= k + 1 planes, then transformed along dims 1 and 2)
+  int d0;              // planes of the volume; d0 >= K + MVN_D0_PF
+  int k;               // PSF planes (taps); the kernel is instantiated for K = k | 1 (a zero tap appended)
+  int kd;              // planes of the tap array
+  int h;               // k / 2
+  long plane;          // bins per plane
+  int stagger;         // workgroup w starts its (cyclic) walk at plane (w * stagger) mod d0: 0 = all at plane 0
+};
+
+#define MVN_D0_PF 4         // planes requested ahead
+#define MVN_D0_MAX_TAPS 33  // largest instantiated K
+
+// acc + a * w (complex): two packed fused multiply-adds on the device
+MVN_HD cfloat mvn_cmac(cfloat acc, cfloat a, cfloat w) {
+#if defined(MVN_PACKED)
+  cfloat t, r;
+  MVN_PK3(t, "v_pk_fma_f32", a, w, acc, "op_sel_hi:[0,1,1]");                                // (a.x w.x, a.x w.y) + acc
+  MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]");  // + (-a.y w.y, a.y w.x)
+  return r;
+#else
+  return cmake(acc.x + a.x * w.x - a.y * w.y, acc.y + a.x * w.y + a.y * w.x);
+#endif
+}
+
+template <int K, int PF>
+struct Dim0Window {
+  cfloat w[K + PF];
+  cfloat tap[K];
+  cfloat bad;  // sum of (x - x) over every input of the column: 0, or NaN once a non-finite value came by
+};
+
+// Non-finite values.  The RL loop lets NaN / Inf flow (0 / 0 and x / 0 quotients, inc/cpu_kernels.h:19-26)
+// and an FFT-based convolution turns ONE such voxel into a volume of NaN, which the update then clamps to
+// minValue everywhere (inc/cpu_kernels.h:76-80) - the reference's, and the oracle's, behaviour.  The last-axis
+// and dim1 transforms have already spread the voxel over its whole plane when this pass runs, so every column
+// meets a non-finite input: a column that did rewrites ALL its outputs as NaN, and the volume comes out as
+// the FFT leg would have left it.
+MVN_HD cfloat mvn_dim0_track(cfloat bad, cfloat v) { return cadd(bad, csub(v, v)); }
+
+template <int K, int PF, int U>
+MVN_HD void mvn_dim0_step(Dim0Window<K, PF>& r, const cfloat* __restrict__ in, cfloat* __restrict__ out, long plane,
+                          int d0, int nn, int& z, int& znew) {
+  constexpr int KW = K + PF;
+  if (nn + U >= d0) return;  // d0 outputs in all, the walk is cyclic
+  cfloat acc = cmake(0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < K; ++j) acc = mvn_cmac(acc, r.w[(j + PF - U + KW) % KW], r.tap[j]);
+  out[(long)z * plane] = acc;
+  // x_0 = in[z + h] runs over every plane of the column once: tracked HERE, where it has long arrived
+  // (at its load the check would stall on the request that was just issued)
+  r.bad = mvn_dim0_track(r.bad, r.w[(PF - U + KW) % KW]);
+  // the oldest value x_{K-1} leaves; in[z + h + PF + 1], x_{-PF} of the next step, takes its slot
+  r.w[(K - 1 + PF - U + KW) % KW] = in[(long)znew * plane];
+  znew = znew + 1 == d0 ? 0 : znew + 1;
+  z = z + 1 == d0 ? 0 : z + 1;
+  if constexpr (U + 1 < KW) mvn_dim0_step<K, PF, U + 1>(r, in, out, plane, d0, nn, z, znew);
+}
+
+// all d0 outputs of bin b, starting at plane z0 and walking cyclically
+template <int K, int PF>
+MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P, long b, int z0 = 0) {
+  constexpr int KW = K + PF;
+  Dim0Window<K, PF> r;
+  r.bad = cmake(0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    int p = j - P.h;
+    p = p < 0 ? p + P.kd : p;
+    r.tap[j] = j < P.k ? P.taps[(long)p * P.plane + b] : cmake(0.f, 0.f);
+  }
+  // at u = 0 (z = z0): slot s holds x_{s - PF} = in[z0 + h + PF - s]
+#pragma unroll
+  for (int s = 0; s < KW; ++s) {
+    int z = z0 + P.h + PF - s;
+    z = z < 0 ? z + P.d0 : (z >= P.d0 ? z - P.d0 : z);
+    r.w[s] = P.in[(long)z * P.plane + b];
+  }
+  int znew = z0 + P.h + PF + 1;
+  if (znew >= P.d0) znew -= P.d0;
+  int zout = z0;
+  // (in and out never alias: the leg is out of place)
+  const cfloat* __restrict__ in = P.in + b;
+  cfloat* __restrict__ out = P.out + b;
+  for (int nn = 0; nn < P.d0; nn += KW) mvn_dim0_step<K, PF, 0>(r, in, out, P.plane, P.d0, nn, zout, znew);
+  if (r.bad.x != 0.f || r.bad.y != 0.f) {  // (NaN != 0): see mvn_dim0_track
+    const float q = r.bad.x != 0.f ? r.bad.x : r.bad.y;
+    for (int z = 0; z < P.d0; ++z) P.out[(long)z * P.plane + b] = cmake(q, q);
+  }
+}
+
+// K the direct kernel is instantiated for: k itself if odd, else k + 1 (one zero tap)
+inline int mvn_dim0_taps_template(int k) { return k | 1; }
+inline bool mvn_dim0_direct_possible(int k, int d0) {
+  const int K = mvn_dim0_taps_template(k);
+  return k >= 1 && K <= MVN_D0_MAX_TAPS && d0 >= K + MVN_D0_PF;
+}
+
+// the instantiated tap counts, for the launch switches of both backends
+#define MVN_D0_TAP_COUNTS(X) X(1) X(3) X(5) X(7) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31) X(33)

@@ -21,7 +21,7 @@ const char* kernel_kind_name(int k) {
   static const char* names[KK_COUNT] = {"rows_r2c",    "rows_c2r",  "rows_fused_div",
                                         "rows_fused_upd", "axis1_fwd", "axis1_inv",
                                         "axis0_fused", "axis0_fwd",  "axis0_inv",
-                                        "nyquist",     "other"};
+                                        "nyquist",     "other",     "axis0_direct"};
   return (k >= 0 && k < KK_COUNT) ? names[k] : "?";
 }
 
@@ -605,6 +605,13 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   if (plan_->nyq_bytes()) work_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
   views_.resize((size_t)num_views);
   spec_tiled_ = plan_->tiles_spectra();
+  // read per engine (A/B runs, tests).  MVN_DIM0_DIRECT_MAX: most PSF planes the direct dim0 leg takes on;
+  // measured at 512^3 x 6 views on MI355X (profiles/r03_dim0_direct.md) the whole iteration is 5 / 4 / 2.5 %
+  // faster than with the fused FFT pass at 5..9 / 15 / 21 planes and equal at 31 (62 packed FMAs per bin:
+  // the pass is then bound by the vector ALUs and the clock they pull down, not by HBM)
+  direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
+  direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", 21);
+  d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
   for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);
 }
@@ -622,10 +629,16 @@ Engine::~Engine() {
     be::dfree(views_[v].nyq1);
     be::dfree(views_[v].spec2);
     be::dfree(views_[v].nyq2);
+    for (int i = 0; i < 2; ++i) {
+      be::dfree(views_[v].taps[i]);
+      be::dfree(views_[v].taps_nyq[i]);
+    }
   }
   be::dfree(psi_);
   be::dfree(work_);
   be::dfree(work_nyq_);
+  be::dfree(work2_);
+  be::dfree(work2_nyq_);
   be::dfree(psi_spec_);
   be::dfree(psi_spec_nyq_);
   be::dfree(embed_scratch_);
@@ -692,16 +705,11 @@ void Engine::upload_volume(float* dst, const float* host, be::stream_t s) {
 }
 
 void Engine::alloc_view(ViewSlot& s) {
-  const size_t mb = plan_->main_bytes(), nb = plan_->nyq_bytes();
+  const size_t mb = plan_->main_bytes();
   if (s.image) return;
   s.image = (float*)be::dmalloc(mb);
   s.weights = (float*)be::dmalloc(mb);
-  s.spec1 = (float*)be::dmalloc(mb);
-  s.spec2 = (float*)be::dmalloc(mb);
-  if (nb) {
-    s.nyq1 = (cfloat*)be::dmalloc(nb);
-    s.nyq2 = (cfloat*)be::dmalloc(nb);
-  }
+  // the PSF buffers (3-D spectra or direct-form taps) are allocated by prepare_psf, which knows the form
   if (plan_->L.RP != plan_->L.d2 || embedded_) {  // odd d2 / embedded stacks: the padding must hold zeros
     be::dzero(s.image, mb, stream_);
     be::dzero(s.weights, mb, stream_);
@@ -746,6 +754,133 @@ void Engine::make_spectrum(const float* d_kernel, const int* kdims, float scale,
   plan_->retile_spectrum((const cfloat*)scratch, (cfloat*)spec, s);
 }
 
+// The dim0 leg runs as a direct convolution when the PSF has at most MVN_D0_MAX_TAPS planes, the volume is
+// deep enough for the kernel's window, and the small plan of the tap arrays transforms dims 1 and 2
+// exactly as the volume's plan does (same kernel family => same position order of the spectra).
+bool Engine::direct_form(const int* kdims) {
+  if (!direct_enabled_ || kdims[0] > direct_max_taps_ || !mvn_dim0_direct_possible(kdims[0], plan_->L.d0)) return false;
+  const int kd = ((kdims[0] + 1 + 15) / 16) * 16;
+  const Plan3D* tp = taps_plan(kd);
+  return tp->fx_rows == plan_->fx_rows && tp->fx_ax1 == plan_->fx_ax1 && tp->L.C == plan_->L.C &&
+         tp->L.RP == plan_->L.RP && tp->L.even == plan_->L.even;
+}
+
+Plan3D* Engine::taps_plan(int kd) {
+  auto it = taps_plans_.find(kd);
+  if (it != taps_plans_.end()) return it->second.get();
+  std::unique_ptr<Plan3D> p(new Plan3D(device_, kd, plan_->L.d1, plan_->L.d2));
+  Plan3D* raw = p.get();
+  taps_plans_[kd] = std::move(p);
+  return raw;
+}
+
+void Engine::prepare_psf(ViewSlot& s, int i, const float* d_kernel, const int* kdims, float* scratch,
+                         bool staging, be::stream_t st) {
+  const Layout& L = plan_->L;
+  for (int d = 0; d < 3; ++d) {
+    const int D = d == 0 ? L.d0 : (d == 1 ? L.d1 : L.d2);
+    if (kdims[d] < 1 || kdims[d] > D) throw std::invalid_argument("mvn: kernel extent must be in [1, image extent]");
+  }
+  if (direct_form(kdims)) {
+    const int kd = ((kdims[0] + 1 + 15) / 16) * 16;
+    Plan3D* tp = taps_plan(kd);
+    if (s.tap_kd[i] != kd) {  // (re)allocate for this depth; the previous arrays may still be read by the stream
+      be::stream_sync(st);
+      be::stream_sync(stream_);
+      be::dfree(s.taps[i]);
+      be::dfree(s.taps_nyq[i]);
+      s.taps[i] = nullptr;
+      s.taps_nyq[i] = nullptr;
+      s.taps[i] = (float*)be::dmalloc(tp->main_bytes());
+      if (tp->nyq_bytes()) s.taps_nyq[i] = (cfloat*)be::dmalloc(tp->nyq_bytes());
+      s.tap_kd[i] = kd;
+    }
+    s.tap_k[i] = 0;  // not valid until the launches below are enqueued
+    // dims 1 and 2 are transformed (un-normalised, both ways), dim0 is not: 1 / (d1 d2)
+    const float scale = (float)(1.0 / ((double)L.d1 * (double)L.d2));
+    be::dzero(s.taps[i], tp->main_bytes(), st);
+    be::launch_scatter_psf(d_kernel, kdims[0], kdims[1], kdims[2], s.taps[i], kd, L.d1, L.d2, tp->L.RP, scale, st);
+    tp->rows_r2c(s.taps[i], (cfloat*)s.taps[i], s.taps_nyq[i], st, nullptr);
+    tp->axis1(MVN_ST_FWD, (cfloat*)s.taps[i], s.taps_nyq[i], st, nullptr);
+    s.tap_k[i] = kdims[0];
+    return;
+  }
+  // 3-D spectrum for the fused FFT pass
+  float*& spec = i == 0 ? s.spec1 : s.spec2;
+  cfloat*& nyq = i == 0 ? s.nyq1 : s.nyq2;
+  if (!spec) {
+    spec = (float*)be::dmalloc(plan_->main_bytes());
+    if (plan_->nyq_bytes()) nyq = (cfloat*)be::dmalloc(plan_->nyq_bytes());
+  }
+  s.tap_k[i] = 0;
+  if (spec_tiled_ && !scratch) {
+    if (!staging) throw std::logic_error("mvn: spectrum scratch missing");
+    if (!stage_spec_scratch_) {  // the main thread iterates on the work volume meanwhile: own scratch, freed
+                                 // with the other staging scratch once the upload stream has drained
+      stage_spec_scratch_ = (float*)be::dmalloc(plan_->main_bytes());
+      stage_scratch_.push_back(stage_spec_scratch_);
+    }
+    scratch = stage_spec_scratch_;
+  }
+  const float scale = (float)(1.0 / (double)L.logical());  // inc/cpu_convolve.h:271-274
+  make_spectrum(d_kernel, kdims, scale, spec, nyq, scratch, st);
+}
+
+void Engine::ensure_work2() {
+  if (work2_) return;
+  work2_ = (float*)be::dmalloc(plan_->main_bytes());
+  if (plan_->nyq_bytes()) work2_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
+}
+
+// the dim0 leg with the direct form of kernel i: in -> out (never in place); the Nyquist plane on sn
+void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out,
+                       cfloat* out_nyq, Profiler* prof, be::stream_t sn) {
+  const Layout& L = plan_->L;
+  Dim0DirectParams p;
+  p.in = in;
+  p.out = out;
+  p.taps = (const cfloat*)s.taps[i];
+  p.d0 = L.d0;
+  p.k = s.tap_k[i];
+  p.kd = s.tap_kd[i];
+  p.h = s.tap_k[i] / 2;
+  p.plane = (long)L.d1 * L.C;
+  p.stagger = d0_stagger_;
+  {
+    ProfScope ps(prof, KK_AXIS0_DIRECT, stream_);
+    be::launch_dim0_direct(p, stream_);
+  }
+  if (L.even) {
+    p.in = in_nyq;
+    p.out = out_nyq;
+    p.taps = s.taps_nyq[i];
+    p.plane = L.d1;
+    ProfScope ps(sn == stream_ ? prof : nullptr, KK_NYQ, sn);
+    be::launch_dim0_direct(p, sn);
+  }
+}
+
+void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {
+  const Plan3D& P = *plan_;
+  if (!s.tap_k[i]) {
+    P.middle_passes((cfloat*)work_, work_nyq_, (const cfloat*)(i == 0 ? s.spec1 : s.spec2), i == 0 ? s.nyq1 : s.nyq2,
+                    stream_, prof, side, spec_tiled_);
+    return;
+  }
+  be::stream_t sn = stream_;
+  if (side && side->s && P.L.even) {
+    side->fork_from(stream_);  // the plane was written by the last-axis pass just enqueued on stream_
+    sn = side->s;
+  }
+  P.axis1(MVN_ST_FWD, (cfloat*)work_, work_nyq_, stream_, prof, sn);
+  ensure_work2();
+  dim0_conv(s, i, (const cfloat*)work_, work_nyq_, (cfloat*)work2_, work2_nyq_, prof, sn);
+  std::swap(work_, work2_);
+  std::swap(work_nyq_, work2_nyq_);
+  P.axis1(MVN_ST_INV, (cfloat*)work_, work_nyq_, stream_, prof, sn);
+  if (sn != stream_) side->join_into(stream_);  // the next last-axis pass on stream_ reads the plane
+}
+
 void Engine::set_view(int v, const float* image, const float* weights, const float* kernel1,
                       const int* k1dims, const float* kernel2, const int* k2dims) {
   if (v < 0 || v >= (int)views_.size()) throw std::out_of_range("mvn: view index");
@@ -754,11 +889,8 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
   alloc_view(s);
   upload_volume(s.image, image, stream_);
   upload_volume(s.weights, weights, stream_);
-  const float scale = (float)(1.0 / (double)plan_->L.logical());  // inc/cpu_convolve.h:271-274
   const float* ks[2] = {kernel1, kernel2};
   const int* kd[2] = {k1dims, k2dims};
-  float* specs[2] = {s.spec1, s.spec2};
-  cfloat* nyqs[2] = {s.nyq1, s.nyq2};
   for (int i = 0; i < 2; ++i) {
     if (psf_resident(s, i, ks[i], kd[i])) continue;
     const size_t kb = sizeof(float) * (size_t)kd[i][0] * (size_t)kd[i][1] * (size_t)kd[i][2];
@@ -767,7 +899,7 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
     try {
       // nothing else runs on this engine during a blocking set_view: the work volume is the scratch
       work_has_psi_spectrum_ = false;
-      make_spectrum(dk, kd[i], scale, specs[i], nyqs[i], work_, stream_);
+      prepare_psf(s, i, dk, kd[i], work_, false, stream_);
     } catch (...) {
       be::stream_sync(stream_);
       be::dfree(dk);
@@ -798,27 +930,20 @@ void Engine::stage_view(int v, const float* image, const float* weights, const f
   ViewSlot& s = views_[(size_t)v];
   upload_volume(s.image, image, upload_stream_);
   upload_volume(s.weights, weights, upload_stream_);
-  const float scale = (float)(1.0 / (double)plan_->L.logical());
   const float* ks[2] = {kernel1, kernel2};
   const int* kd[2] = {k1dims, k2dims};
-  float* specs[2] = {s.spec1, s.spec2};
-  cfloat* nyqs[2] = {s.nyq1, s.nyq2};
   for (int i = 0; i < 2; ++i) {
     if (psf_resident(s, i, ks[i], kd[i])) continue;
     const size_t kb = sizeof(float) * (size_t)kd[i][0] * (size_t)kd[i][1] * (size_t)kd[i][2];
     float* dk = (float*)be::dmalloc(kb);
     stage_scratch_.push_back(dk);  // freed in finish_staging(), after the stream has drained
     be::h2d(dk, ks[i], kb, upload_stream_);
-    float* scratch = nullptr;
-    if (spec_tiled_) {  // the main thread iterates on the work volume meanwhile: own scratch, freed
-                        // with the other staging scratch once the upload stream has drained
-      if (!stage_spec_scratch_) {
-        stage_spec_scratch_ = (float*)be::dmalloc(plan_->main_bytes());
-        stage_scratch_.push_back(stage_spec_scratch_);
-      }
-      scratch = stage_spec_scratch_;
+    try {
+      prepare_psf(s, i, dk, kd[i], nullptr, true, upload_stream_);
+    } catch (...) {
+      s.kcopy[i].clear();  // the resident form is in an unknown state: never a cache hit
+      throw;
     }
-    make_spectrum(dk, kd[i], scale, specs[i], nyqs[i], scratch, upload_stream_);
   }
   be::event_record(staged_ev_[(size_t)v], upload_stream_);
   s.set = true;
@@ -896,7 +1021,6 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   if (prof_.enabled && (pair_counter_++ % (prof_.sample_every > 0 ? prof_.sample_every : 1)) == 0)
     prof = &prof_;
   const Plan3D& P = *plan_;
-  cfloat* W = (cfloat*)work_;
   static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;  // A/B knob for experiments
   const bool fuse = P.can_fuse_rows() && !no_fuse;
 
@@ -927,23 +1051,24 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;  // A/B knob
   static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
   SideStream* side = (no_side || P.main_bytes() <= side_min_bytes) ? nullptr : &side_;
-  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, W, work_nyq_, stream_, prof);
+  // (work_ / work_nyq_ are re-read after every middle(): the direct dim0 leg swaps the two work volumes)
+  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, (cfloat*)work_, work_nyq_, stream_, prof);
   work_has_psi_spectrum_ = false;
-  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, side, spec_tiled_);
+  middle(s, 0, prof, side);
   // view / blurred, handed to convolution 2 as its last-axis spectrum
   if (fuse) {
-    P.rows_c2r_r2c(W, work_nyq_, e1, stream_, prof);
+    P.rows_c2r_r2c((cfloat*)work_, work_nyq_, e1, stream_, prof);
   } else {
-    P.rows_c2r(W, work_nyq_, work_, e1, stream_, prof);
-    P.rows_r2c(work_, W, work_nyq_, stream_, prof);
+    P.rows_c2r((const cfloat*)work_, work_nyq_, work_, e1, stream_, prof);
+    P.rows_r2c(work_, (cfloat*)work_, work_nyq_, stream_, prof);
   }
   // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
-  P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof, side, spec_tiled_);
+  middle(s, 1, prof, side);
   if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
-    P.rows_c2r_r2c(W, work_nyq_, e2, stream_, prof);
+    P.rows_c2r_r2c((cfloat*)work_, work_nyq_, e2, stream_, prof);
     work_has_psi_spectrum_ = true;
   } else {
-    P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
+    P.rows_c2r((const cfloat*)work_, work_nyq_, psi_, e2, stream_, prof);
   }
 }
 
@@ -962,9 +1087,16 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
   static const bool graphs_on = env_int("MVN_GRAPH", 0) != 0 && be::graphs_supported();
   static const size_t graph_max_bytes = (size_t)env_int("MVN_GRAPH_MAX_MB", 160) << 20;
   static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;
-  const bool use_graph = graphs_on && iterations >= 3 && !prof_.enabled && plan_->can_fuse_rows() &&
-                         !no_fuse && plan_->main_bytes() <= graph_max_bytes;
+  // (a captured sweep holds buffer addresses: the two work volumes must be back in their roles after it,
+  // i.e. the sweep must contain an even number of direct dim0 legs)
+  bool use_graph = graphs_on && iterations >= 3 && !prof_.enabled && plan_->can_fuse_rows() &&
+                   !no_fuse && plan_->main_bytes() <= graph_max_bytes;
   for (int it = 0; it < iterations; ++it) {
+    if (use_graph && it == 1) {  // every view has been staged by now: its PSF forms are known
+      int swaps = 0;
+      for (int v = 0; v < V; ++v) swaps += (views_[(size_t)v].tap_k[0] != 0) + (views_[(size_t)v].tap_k[1] != 0);
+      use_graph = swaps % 2 == 0;
+    }
     if (use_graph && it >= 1 && it < iterations - 1) {
       if (sweep_graph_ && (graph_lambda_ != lambda || graph_min_ != min_value ||
                            graph_guard_ != quotient_guard_)) {
@@ -1069,7 +1201,6 @@ void Engine::compute_delta_head(double lambda, float min_value) {
   // event pairs around every launch cost ~3 % of a sweep: sample like iterate() does
   const int every = prof_.sample_every > 0 ? prof_.sample_every : 1;
   Profiler* prof = (prof_.enabled && (pair_counter_++ % every) == 0) ? &prof_ : nullptr;
-  cfloat* W = (cfloat*)work_;
   if (!psi_spec_) {
     psi_spec_ = (float*)be::dmalloc(P.main_bytes());
     if (P.nyq_bytes()) psi_spec_nyq_ = (cfloat*)be::dmalloc(P.nyq_bytes());
@@ -1112,20 +1243,22 @@ void Engine::compute_delta_head(double lambda, float min_value) {
     // stream (forked per view: the previous view's last pass still reads work_nyq_, and the
     // chunk-fed spectrum of psi was written on the main stream)
     if (use_side) side_.fork_from(stream_);
-    P.axis0(MVN_ST_FWD_MUL_INV, W, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
-            (const cfloat*)psi_spec_, psi_spec_nyq_, spec_tiled_);
-    P.axis1(MVN_ST_INV, W, work_nyq_, stream_, prof, sn);
+    if (s.tap_k[0])
+      dim0_conv(s, 0, (const cfloat*)psi_spec_, psi_spec_nyq_, (cfloat*)work_, work_nyq_, prof, sn);
+    else
+      P.axis0(MVN_ST_FWD_MUL_INV, (cfloat*)work_, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
+              (const cfloat*)psi_spec_, psi_spec_nyq_, spec_tiled_);
+    P.axis1(MVN_ST_INV, (cfloat*)work_, work_nyq_, stream_, prof, sn);
     if (use_side) side_.join_into(stream_);
     if (fuse) {
-      P.rows_c2r_r2c(W, work_nyq_, e1, stream_, prof);
+      P.rows_c2r_r2c((cfloat*)work_, work_nyq_, e1, stream_, prof);
     } else {
-      P.rows_c2r(W, work_nyq_, work_, e1, stream_, prof);
-      P.rows_r2c(work_, W, work_nyq_, stream_, prof);
+      P.rows_c2r((const cfloat*)work_, work_nyq_, work_, e1, stream_, prof);
+      P.rows_r2c(work_, (cfloat*)work_, work_nyq_, stream_, prof);
     }
-    P.middle_passes(W, work_nyq_, (const cfloat*)s.spec2, s.nyq2, stream_, prof,
-                    use_side ? &side_ : nullptr, spec_tiled_);
+    middle(s, 1, prof, use_side ? &side_ : nullptr);
     if (v + 1 < V) {
-      P.rows_c2r(W, work_nyq_, psi_, e2, stream_, prof);
+      P.rows_c2r((const cfloat*)work_, work_nyq_, psi_, e2, stream_, prof);
     } else {  // the last view's final pass is launched chunk by chunk (compute_delta_chunk)
       tail_epi_ = e2;
       tail_prof_ = prof;

@@ -34,6 +34,7 @@ enum KernelKind {
   KK_AXIS0_INV,
   KK_NYQ,
   KK_OTHER,
+  KK_AXIS0_DIRECT,  // dim0 leg as a direct convolution with the PSF's planes (mvn_dim0_direct.hpp)
   KK_COUNT
 };
 const char* kernel_kind_name(int k);
@@ -203,6 +204,13 @@ struct ViewSlot {
   // brings the same PSF for this slot (Fiji's block-after-block calls do) skips the preparation
   std::vector<float> kcopy[2];
   int kdims[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  // direct dim0 form of kernel i (mvn_dim0_direct.hpp): its planes after the last-axis and dim1
+  // transforms, [tap_kd][d1][C] (+ Nyquist [tap_kd][d1]), pre-scaled by 1 / (d1 d2).  tap_k = PSF planes
+  // when this form is what the slot holds for kernel i, 0 when the 3-D spectrum (spec / nyq) is.
+  float* taps[2] = {nullptr, nullptr};
+  cfloat* taps_nyq[2] = {nullptr, nullptr};
+  int tap_k[2] = {0, 0};
+  int tap_kd[2] = {0, 0};
 };
 
 class Engine {
@@ -300,6 +308,26 @@ class Engine {
   // the plan wants it) the tile-contiguous re-ordering through `scratch` (one volume)
   void make_spectrum(const float* d_kernel, const int* kdims, float scale, float* spec, cfloat* nyq,
                      float* scratch, be::stream_t s);
+  // Kernel i of slot s from its device-resident copy: the direct dim0 form (taps) where the PSF is thin
+  // enough along dim0 (direct_form), the 3-D spectrum otherwise; buffers are allocated on first use.
+  // `scratch` (one volume, or nullptr = allocate one with the staging scratch) serves the re-tiling of a
+  // 3-D spectrum.
+  void prepare_psf(ViewSlot& s, int i, const float* d_kernel, const int* kdims, float* scratch, bool staging,
+                   be::stream_t st);
+  bool direct_form(const int* kdims);
+  Plan3D* taps_plan(int kd);
+  // dim1 forward -> dim0 leg (direct or fused FFT) -> dim1 inverse on the work volume, with kernel i of s
+  void middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side);
+  void dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out, cfloat* out_nyq,
+                 Profiler* prof, be::stream_t sn);
+  void ensure_work2();
+  bool direct_enabled_ = true;
+  int d0_stagger_ = 0;
+  int direct_max_taps_ = 21;
+  std::map<int, std::unique_ptr<Plan3D>> taps_plans_;  // (kd, d1, d2) plans of the tap arrays, private to the engine
+  // second work volume: the direct dim0 leg is out of place, work_ and work2_ swap roles after it
+  float* work2_ = nullptr;
+  cfloat* work2_nyq_ = nullptr;
   bool spec_tiled_ = false;
   float* stage_spec_scratch_ = nullptr;  // owned by stage_scratch_
   void wait_staged(int v);

@@ -141,6 +141,16 @@ __global__ void __launch_bounds__((FxSplitCfg<N>::NT)) kx_strided_split(const St
   fx_strided_split_body<N, MODE>(p, (long)blockIdx.x, p.nblocks, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
+// direct dim0 convolution (mvn_dim0_direct.hpp): one bin per work item, all of dim0
+template <int K, int PF = MVN_D0_PF>
+__global__ void __launch_bounds__(256) kd_dim0(const Dim0DirectParams p) {
+  const long b = (long)blockIdx.x * 256 + threadIdx.x;
+  // workgroups start their cyclic walk along dim0 at different planes (p.stagger): all of them on one
+  // plane at a time keep the whole chip on 1 MB in and 1 MB out
+  const int z0 = p.stagger > 0 ? (int)(((long)blockIdx.x * p.stagger) % p.d0) : 0;
+  if (b < p.plane) mvn_dim0_direct_column<K, PF>(p, b, z0);
+}
+
 __global__ void k_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
                               int D1, int D2, long pitch, float scale) {
   const long total = (long)k0 * k1 * k2;
@@ -714,6 +724,21 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
     case MVN_ST_FWD_MUL_INV: MVN_DISPATCH_T(p.T, (k_strided<MVN_ST_FWD_MUL_INV, TT, false>)); break;
     default: throw std::invalid_argument("mvn: unknown strided mode");
   }
+}
+
+void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
+  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out)
+    throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
+  check_aligned16(p.in, "input");  // (8-byte accesses; the volumes are 16-byte aligned anyway)
+  const long nblocks = (p.plane + 255) / 256;
+  if (nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
+  switch (mvn_dim0_taps_template(p.k)) {
+#define X(K) case K: hipLaunchKernelGGL(kd_dim0<K>, dim3((unsigned)nblocks), dim3(256), 0, hs(s), p); break;
+    MVN_D0_TAP_COUNTS(X)
+#undef X
+    default: throw std::invalid_argument("mvn: no direct dim0 kernel for this tap count");
+  }
+  HIP_CHECK(hipGetLastError());
 }
 
 static unsigned flat_grid(size_t n, int block) {

@@ -765,3 +765,65 @@ def test_submit_wait_pipeline_equals_blocking_calls(emu, capfd):
         emu.set_pad_mode(None)
     capfd.readouterr()
     emu.l.mvn_release_cached_engines()
+
+
+@pytest.mark.parametrize("k0", [1, 2, 3, 4, 9, 16, 21, 33])
+def test_direct_dim0_leg_vs_fft_leg_and_oracle(emu, monkeypatch, k0):
+    # mvn_dim0_direct.hpp: the dim0 leg as a direct convolution with the PSF's planes (odd and even
+    # depths, the largest instantiated one, a zero tap appended for even depths), with staggered and
+    # unstaggered walks, against the fused FFT leg of the same engine and against the oracle;
+    # sequential sweep and simultaneous step, lambda 0 and > 0
+    shape = (40, 12, 18)  # d0 >= 33 + 4
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (k0, 5, 3), seed=50 + k0)
+    k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]  # an asymmetric second kernel of the same depth
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MAX", "33")
+    results = {}
+    for tag, env in (("fft", {"MVN_DIM0_DIRECT": "0"}), ("direct", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "0"}),
+                     ("staggered", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "7"})):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        emu.l.mvn_release_cached_engines()
+        for lam in (0.0, 0.006):
+            h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+            results[(tag, lam)] = emu.gpu_deconvolve(psi0, h)
+        e = emu.engine(shape, 2)
+        for v in range(2):
+            e.set_view(v, views[v], w[v], k1[v], k2[v])
+        e.set_psi(psi0)
+        for _ in range(2):
+            e.compute_delta(0.006, 1e-4)
+            e.apply_delta()
+        results[(tag, "sim")] = e.get_psi()
+        e.close()
+    emu.l.mvn_release_cached_engines()
+    for lam in (0.0, 0.006):
+        ref = orc.cpu_deconvolve(psi0, WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3), 4)
+        for tag in ("fft", "direct", "staggered"):
+            assert np.abs(results[(tag, lam)] - ref).max() <= 1e-4 * np.abs(ref).max(), (tag, lam)
+        assert np.array_equal(results[("direct", lam)], results[("staggered", lam)])  # same sums, another start plane
+    ref = orc.cpu_deconvolve_simultaneous(psi0, WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2), 4)
+    for tag in ("fft", "direct", "staggered"):
+        assert np.abs(results[(tag, "sim")] - ref).max() <= 1e-4 * np.abs(ref).max(), tag
+
+
+def test_direct_dim0_leg_limits_and_nonfinite(emu, monkeypatch):
+    # too deep a PSF / too shallow a volume fall back to the FFT leg; a non-finite voxel floods the
+    # volume exactly as the FFT leg does (the update then clamps everything to minValue)
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MAX", "33")
+    emu.l.mvn_release_cached_engines()
+    for shape, kshape in (((40, 10, 12), (35, 3, 3)), ((12, 10, 12), (9, 3, 3)), ((8, 6, 10), (3, 3, 3))):
+        _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=7)
+        h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+        got = emu.gpu_deconvolve(psi0, h)
+        ref = orc.cpu_deconvolve(psi0, h, 4)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), shape
+    shape = (24, 10, 12)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 1, (5, 3, 3), seed=8)
+    views[0][17, 3, 4] = 0.0
+    psi_bad = psi0.copy()
+    psi_bad[5, 5, 5] = np.inf
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    got = emu.gpu_deconvolve(psi_bad, h)
+    ref = orc.cpu_deconvolve(psi_bad, h, 2)
+    assert np.array_equal(got, ref, equal_nan=True) and np.isfinite(got).sum() >= got.size - 1  # all clamped; the voxel itself stays NaN
+    emu.l.mvn_release_cached_engines()

@@ -728,8 +728,11 @@ def test_slab_engine_one_rank_equals_resident_engine(gpu, shape, V):
     nm, nn = se.buffer_sizes()
 
     def copy(dst, src, n):
+        # a device-to-device hipMemcpy may return before the copy has run, and the engine's stream is
+        # non-blocking (no implicit ordering against the null stream): drain the device explicitly
         if n:
             assert hip.hipMemcpy(dst, src, n * 4, D2D) == 0
+            assert hip.hipDeviceSynchronize() == 0
 
     its = 2
     for it in range(its):
@@ -1211,3 +1214,61 @@ def test_submit_wait_pipelines_three_blocks_bit_for_bit(gpu):
     finally:
         gpu.set_pad_mode(before)
         gpu.check(gpu.l.mvn_release_cached_engines())
+
+
+_DIRECT_CHILD = r"""
+import os, sys
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from libmultiviewnative_amd import native
+from libmultiviewnative_amd.abi import WorkspaceHolder
+from oracle import binding as orc
+from ref_fixtures import realistic_views
+gpu = native.lib()
+assert gpu.backend_name() == "hip-gfx950"
+worst = 0.0
+for shape, kshape in [((64, 64, 64), (1, 5, 5)), ((64, 64, 64), (4, 5, 3)), ((96, 32, 64), (15, 7, 5)),
+                      ((64, 48, 512), (21, 5, 9)), ((80, 24, 40), (33, 3, 3)), ((40, 13, 17), (9, 5, 3))]:
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=sum(kshape))
+    k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+        got = gpu.gpu_deconvolve(psi0, h)
+        ref = orc.cpu_deconvolve(psi0, h, 8)
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        worst = max(worst, err)
+        assert err <= 1e-4, (shape, kshape, lam, err)
+    e = gpu.engine(shape, 2)
+    for v in range(2):
+        e.set_view(v, views[v], w[v], k1[v], k2[v])
+    e.set_psi(psi0)
+    for _ in range(2):
+        e.compute_delta(0.006, 1e-4)
+        e.apply_delta()
+    got = e.get_psi()
+    e.close()
+    ref = orc.cpu_deconvolve_simultaneous(psi0, WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2), 8)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), ("simultaneous", shape, kshape)
+# a non-finite voxel floods the volume as the FFT leg does
+shape = (48, 16, 32)
+_, views, k1, k2, w, psi0 = realistic_views(shape, 1, (5, 3, 3), seed=8)
+psi_bad = psi0.copy(); psi_bad[5, 5, 5] = np.inf
+h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+assert np.array_equal(gpu.gpu_deconvolve(psi_bad, h), orc.cpu_deconvolve(psi_bad, h, 2), equal_nan=True)
+print("direct child ok", os.environ.get("MVN_DIM0_DIRECT"), "%.2e" % worst)
+"""
+
+
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_direct_dim0_leg_in_a_child_process(gpu, direct):
+    # mvn_dim0_direct.hpp on the GPU: PSF depths 1 .. 33 (odd, even, the largest instantiated), d2 = 512
+    # wave-row shapes and odd extents, sequential and simultaneous loops, against the oracle -- and the
+    # same cases with the leg switched off (fused FFT pass), which is what deeper PSFs (31 planes: the
+    # headline) run by default.  Child processes: the switches are read when an engine is created.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVN_DIM0_DIRECT=direct, MVN_DIM0_DIRECT_MAX="33")
+    r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD, root], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "direct child ok " + direct in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 for cfg in "$@"; do
   echo "== $cfg"
-  ( if [ "$cfg" != "-" ]; then IFS=, ; for kv in $cfg; do export "$kv"; done; fi
+  ( if [ "$cfg" != "-" ]; then IFS=, ; for kv in $cfg; do export "$kv"; done; unset IFS; fi
     python bench.py --simultaneous --no-side --no-cpu-baseline --steps ${AB_STEPS:-20} --warmup 3 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:

@@ -406,14 +406,20 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t 
 }
 
 void launch_dim0_direct(const Dim0DirectParams& p, stream_t) {
-  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out)
+  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out ||
+      p.plane2 < 0 || (p.plane2 > 0 && (!p.in2 || !p.out2 || !p.taps2 || p.in2 == p.out2)))
     throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
   switch (mvn_dim0_taps_template(p.k)) {
 #define X(K)                                                                        \
   case K: {                                                                         \
     _Pragma("omp parallel for schedule(static)")                                    \
-    for (long b = 0; b < p.plane; ++b)                                              \
-      mvn_dim0_direct_column<K, MVN_D0_PF>(p, b, p.stagger > 0 ? (int)(((b / 256) * p.stagger) % p.d0) : 0); \
+    for (long g = 0; g < mvn_dim0_items(p); ++g) {                                  \
+      Dim0DirectParams q;                                                           \
+      long b;                                                                       \
+      int zs, nout;                                                                 \
+      if (mvn_dim0_select(p, g, p.stagger > 0 ? (int)(((g / 256) * p.stagger) % p.d0) : 0, q, b, zs, nout)) \
+        mvn_dim0_direct_column<K, MVN_D0_PF>(q, b, zs, nout);                       \
+    }                                                                               \
   } break;
     MVN_D0_TAP_COUNTS(X)
 #undef X

@@ -36,7 +36,48 @@ struct Dim0DirectParams {
   int h;               // k / 2
   long plane;          // bins per plane
   int stagger;         // workgroup w starts its (cyclic) walk at plane (w * stagger) mod d0: 0 = all at plane 0
+  // The Nyquist planes of the split layout ride in the same launch: bins [plane, plane + plane2) are the
+  // bins of a second set of arrays with plane2 bins per plane (plane2 = 0: none).  A separate two-workgroup
+  // launch on the side stream ran as long as the whole main launch (every work item walks all of dim0) and
+  // slowed it by a third (0.30 against 0.22 ms at 512^3, K = 31).
+  const cfloat* in2;
+  cfloat* out2;
+  const cfloat* taps2;
+  long plane2;
+  int seg2;  // the second set's columns are cut into pieces of seg2 output planes, one work item each: a column
+             // walked by ONE work item takes as long as the whole launch, and this set has only plane2 of them
 };
+
+// work item `g` of a launch: the arrays it belongs to, the bin it owns there and the output planes
+// [z0, z0 + nout) it produces (cyclically)
+MVN_HD bool mvn_dim0_select(const Dim0DirectParams& P, long g, int wg_start, Dim0DirectParams& Q, long& b, int& z0,
+                            int& nout) {
+  Q = P;
+  if (g < P.plane) {
+    b = g;
+    z0 = wg_start;
+    nout = P.d0;
+    return true;
+  }
+  if (P.plane2 <= 0) return false;
+  const long g2 = g - P.plane;
+  const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
+  const long piece = g2 / P.plane2;
+  b = g2 - piece * P.plane2;
+  z0 = (int)(piece * seg);
+  if (z0 >= P.d0) return false;
+  nout = P.d0 - z0 < seg ? P.d0 - z0 : seg;
+  Q.in = P.in2;
+  Q.out = P.out2;
+  Q.taps = P.taps2;
+  Q.plane = P.plane2;
+  return true;
+}
+// work items of a launch
+inline long mvn_dim0_items(const Dim0DirectParams& P) {
+  const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
+  return P.plane + (P.plane2 > 0 ? P.plane2 * ((P.d0 + seg - 1) / seg) : 0);
+}
 
 #define MVN_D0_PF 4         // planes requested ahead
 #define MVN_D0_MAX_TAPS 33  // largest instantiated K
@@ -70,9 +111,9 @@ MVN_HD cfloat mvn_dim0_track(cfloat bad, cfloat v) { return cadd(bad, csub(v, v)
 
 template <int K, int PF, int U>
 MVN_HD void mvn_dim0_step(Dim0Window<K, PF>& r, const cfloat* __restrict__ in, cfloat* __restrict__ out, long plane,
-                          int d0, int nn, int& z, int& znew) {
+                          int d0, int nout, int nn, int& z, int& znew) {
   constexpr int KW = K + PF;
-  if (nn + U >= d0) return;  // d0 outputs in all, the walk is cyclic
+  if (nn + U >= nout) return;  // nout outputs in all, the walk is cyclic
   cfloat acc = cmake(0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < K; ++j) acc = mvn_cmac(acc, r.w[(j + PF - U + KW) % KW], r.tap[j]);
@@ -84,12 +125,12 @@ MVN_HD void mvn_dim0_step(Dim0Window<K, PF>& r, const cfloat* __restrict__ in, c
   r.w[(K - 1 + PF - U + KW) % KW] = in[(long)znew * plane];
   znew = znew + 1 == d0 ? 0 : znew + 1;
   z = z + 1 == d0 ? 0 : z + 1;
-  if constexpr (U + 1 < KW) mvn_dim0_step<K, PF, U + 1>(r, in, out, plane, d0, nn, z, znew);
+  if constexpr (U + 1 < KW) mvn_dim0_step<K, PF, U + 1>(r, in, out, plane, d0, nout, nn, z, znew);
 }
 
-// all d0 outputs of bin b, starting at plane z0 and walking cyclically
+// outputs [z0, z0 + nout) (cyclically) of bin b
 template <int K, int PF>
-MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P, long b, int z0 = 0) {
+MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P, long b, int z0, int nout) {
   constexpr int KW = K + PF;
   Dim0Window<K, PF> r;
   r.bad = cmake(0.f, 0.f);
@@ -112,10 +153,16 @@ MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P, long b, int z0 = 0
   // (in and out never alias: the leg is out of place)
   const cfloat* __restrict__ in = P.in + b;
   cfloat* __restrict__ out = P.out + b;
-  for (int nn = 0; nn < P.d0; nn += KW) mvn_dim0_step<K, PF, 0>(r, in, out, P.plane, P.d0, nn, zout, znew);
+  for (int nn = 0; nn < nout; nn += KW) mvn_dim0_step<K, PF, 0>(r, in, out, P.plane, P.d0, nout, nn, zout, znew);
   if (r.bad.x != 0.f || r.bad.y != 0.f) {  // (NaN != 0): see mvn_dim0_track
     const float q = r.bad.x != 0.f ? r.bad.x : r.bad.y;
-    for (int z = 0; z < P.d0; ++z) P.out[(long)z * P.plane + b] = cmake(q, q);
+    // (whole columns - the main array's - thereby turn NaN entirely, which is what makes the volume come out
+    // all NaN after the passes that follow; a PIECE of a column rewrites its own outputs only)
+    int z = z0;
+    for (int n = 0; n < nout; ++n) {
+      P.out[(long)z * P.plane + b] = cmake(q, q);
+      z = z + 1 == P.d0 ? 0 : z + 1;
+    }
   }
 }
 

@@ -605,12 +605,11 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   if (plan_->nyq_bytes()) work_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
   views_.resize((size_t)num_views);
   spec_tiled_ = plan_->tiles_spectra();
-  // read per engine (A/B runs, tests).  MVN_DIM0_DIRECT_MAX: most PSF planes the direct dim0 leg takes on;
-  // measured at 512^3 x 6 views on MI355X (profiles/r03_dim0_direct.md) the whole iteration is 5 / 4 / 2.5 %
-  // faster than with the fused FFT pass at 5..9 / 15 / 21 planes and equal at 31 (62 packed FMAs per bin:
-  // the pass is then bound by the vector ALUs and the clock they pull down, not by HBM)
+  // read per engine (A/B runs, tests).  MVN_DIM0_DIRECT_MAX: most PSF planes the direct dim0 leg takes on
+  // (MVN_D0_MAX_TAPS = 33 are instantiated); measured at 512^3 x 6 views on MI355X (profiles/r03_dim0_direct.md)
+  // the whole iteration is 6.7 / 4.1 % faster than with the fused FFT pass at 15 / 31 planes
   direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
-  direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", 21);
+  direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
   d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
   for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);
@@ -832,9 +831,10 @@ void Engine::ensure_work2() {
   if (plan_->nyq_bytes()) work2_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
 }
 
-// the dim0 leg with the direct form of kernel i: in -> out (never in place); the Nyquist plane on sn
+// the dim0 leg with the direct form of kernel i: in -> out (never in place), main array and Nyquist plane in
+// ONE launch on the engine's stream
 void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out,
-                       cfloat* out_nyq, Profiler* prof, be::stream_t sn) {
+                       cfloat* out_nyq, Profiler* prof) {
   const Layout& L = plan_->L;
   Dim0DirectParams p;
   p.in = in;
@@ -846,18 +846,13 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   p.h = s.tap_k[i] / 2;
   p.plane = (long)L.d1 * L.C;
   p.stagger = d0_stagger_;
-  {
-    ProfScope ps(prof, KK_AXIS0_DIRECT, stream_);
-    be::launch_dim0_direct(p, stream_);
-  }
-  if (L.even) {
-    p.in = in_nyq;
-    p.out = out_nyq;
-    p.taps = s.taps_nyq[i];
-    p.plane = L.d1;
-    ProfScope ps(sn == stream_ ? prof : nullptr, KK_NYQ, sn);
-    be::launch_dim0_direct(p, sn);
-  }
+  p.in2 = L.even ? in_nyq : nullptr;
+  p.out2 = L.even ? out_nyq : nullptr;
+  p.taps2 = L.even ? s.taps_nyq[i] : nullptr;
+  p.plane2 = L.even ? L.d1 : 0;
+  p.seg2 = 16;
+  ProfScope ps(prof, KK_AXIS0_DIRECT, stream_);
+  be::launch_dim0_direct(p, stream_);
 }
 
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {
@@ -867,18 +862,20 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
                     stream_, prof, side, spec_tiled_);
     return;
   }
-  be::stream_t sn = stream_;
-  if (side && side->s && P.L.even) {
-    side->fork_from(stream_);  // the plane was written by the last-axis pass just enqueued on stream_
-    sn = side->s;
-  }
+  const bool use_side = side && side->s && P.L.even;
+  be::stream_t sn = use_side ? side->s : stream_;
+  // the dim1 passes of the Nyquist plane ride on the side stream beside those of the main array; the dim0 leg
+  // takes both in one launch on stream_, so the side stream joins before it and forks again behind it
+  if (use_side) side->fork_from(stream_);  // the plane was written by the last-axis pass just enqueued on stream_
   P.axis1(MVN_ST_FWD, (cfloat*)work_, work_nyq_, stream_, prof, sn);
+  if (use_side) side->join_into(stream_);
   ensure_work2();
-  dim0_conv(s, i, (const cfloat*)work_, work_nyq_, (cfloat*)work2_, work2_nyq_, prof, sn);
+  dim0_conv(s, i, (const cfloat*)work_, work_nyq_, (cfloat*)work2_, work2_nyq_, prof);
   std::swap(work_, work2_);
   std::swap(work_nyq_, work2_nyq_);
+  if (use_side) side->fork_from(stream_);
   P.axis1(MVN_ST_INV, (cfloat*)work_, work_nyq_, stream_, prof, sn);
-  if (sn != stream_) side->join_into(stream_);  // the next last-axis pass on stream_ reads the plane
+  if (use_side) side->join_into(stream_);  // the next last-axis pass on stream_ reads the plane
 }
 
 void Engine::set_view(int v, const float* image, const float* weights, const float* kernel1,
@@ -1242,12 +1239,16 @@ void Engine::compute_delta_head(double lambda, float min_value) {
     // convolution 1 from the shared spectrum of psi; the Nyquist-plane launches ride on the side
     // stream (forked per view: the previous view's last pass still reads work_nyq_, and the
     // chunk-fed spectrum of psi was written on the main stream)
-    if (use_side) side_.fork_from(stream_);
-    if (s.tap_k[0])
-      dim0_conv(s, 0, (const cfloat*)psi_spec_, psi_spec_nyq_, (cfloat*)work_, work_nyq_, prof, sn);
-    else
+    if (s.tap_k[0]) {
+      // (the shared spectrum of psi may still be in the making on the side stream: v == 0)
+      if (use_side && v == 0) side_.join_into(stream_);
+      dim0_conv(s, 0, (const cfloat*)psi_spec_, psi_spec_nyq_, (cfloat*)work_, work_nyq_, prof);
+      if (use_side) side_.fork_from(stream_);
+    } else {
+      if (use_side) side_.fork_from(stream_);
       P.axis0(MVN_ST_FWD_MUL_INV, (cfloat*)work_, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
               (const cfloat*)psi_spec_, psi_spec_nyq_, spec_tiled_);
+    }
     P.axis1(MVN_ST_INV, (cfloat*)work_, work_nyq_, stream_, prof, sn);
     if (use_side) side_.join_into(stream_);
     if (fuse) {

@@ -319,11 +319,11 @@ class Engine {
   // dim1 forward -> dim0 leg (direct or fused FFT) -> dim1 inverse on the work volume, with kernel i of s
   void middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side);
   void dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out, cfloat* out_nyq,
-                 Profiler* prof, be::stream_t sn);
+                 Profiler* prof);
   void ensure_work2();
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;
-  int direct_max_taps_ = 21;
+  int direct_max_taps_ = MVN_D0_MAX_TAPS;
   std::map<int, std::unique_ptr<Plan3D>> taps_plans_;  // (kd, d1, d2) plans of the tap arrays, private to the engine
   // second work volume: the direct dim0 leg is out of place, work_ and work2_ swap roles after it
   float* work2_ = nullptr;

@@ -144,11 +144,16 @@ __global__ void __launch_bounds__((FxSplitCfg<N>::NT)) kx_strided_split(const St
 // direct dim0 convolution (mvn_dim0_direct.hpp): one bin per work item, all of dim0
 template <int K, int PF = MVN_D0_PF>
 __global__ void __launch_bounds__(256) kd_dim0(const Dim0DirectParams p) {
-  const long b = (long)blockIdx.x * 256 + threadIdx.x;
   // workgroups start their cyclic walk along dim0 at different planes (p.stagger): all of them on one
   // plane at a time keep the whole chip on 1 MB in and 1 MB out
   const int z0 = p.stagger > 0 ? (int)(((long)blockIdx.x * p.stagger) % p.d0) : 0;
-  if (b < p.plane) mvn_dim0_direct_column<K, PF>(p, b, z0);
+  Dim0DirectParams q;
+  long b;
+  int zs, nout;
+  // (the main plane is a multiple of the workgroup size in every fixed-kernel layout; a workgroup that
+  // straddles the boundary just has lanes on both sets of arrays)
+  if (mvn_dim0_select(p, (long)blockIdx.x * 256 + threadIdx.x, z0, q, b, zs, nout))
+    mvn_dim0_direct_column<K, PF>(q, b, zs, nout);
 }
 
 __global__ void k_scatter_psf(const float* kernel, int k0, int k1, int k2, float* target, int D0,
@@ -727,10 +732,11 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
 }
 
 void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
-  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out)
+  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out ||
+      p.plane2 < 0 || (p.plane2 > 0 && (!p.in2 || !p.out2 || !p.taps2 || p.in2 == p.out2)))
     throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
   check_aligned16(p.in, "input");  // (8-byte accesses; the volumes are 16-byte aligned anyway)
-  const long nblocks = (p.plane + 255) / 256;
+  const long nblocks = (mvn_dim0_items(p) + 255) / 256;
   if (nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
   switch (mvn_dim0_taps_template(p.k)) {
 #define X(K) case K: hipLaunchKernelGGL(kd_dim0<K>, dim3((unsigned)nblocks), dim3(256), 0, hs(s), p); break;

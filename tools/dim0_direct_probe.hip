@@ -93,6 +93,15 @@ __global__ void __launch_bounds__(256) kd_dim0(const Dim0DirectParams p) {
   if (b < p.plane) mvn_dim0_direct_column<K, MVN_D0_PF>(p, b);
 }
 
+// plain 1 read + 1 write stream (what a dim1 pass is to the memory system), to alternate with the direct leg
+__global__ void __launch_bounds__(256) k_stream(const float4* __restrict__ a, float4* __restrict__ b, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 v = a[i];
+    v.x += 1.f;
+    b[i] = v;
+  }
+}
+
 template <int K, int PF, int NACC>
 static void run(const cfloat* in, cfloat* out, const cfloat* taps, int d0, long plane, int segs, const std::vector<float>& hin,
                 const std::vector<float>& htaps, bool check) {
@@ -189,6 +198,32 @@ int main(int argc, char** argv) {
       std::printf("   probe form:");
       for (int i = 0; i < 8; ++i) std::printf(" %.3f", tq[i]);
       std::printf("\n");
+    }
+  }
+  {
+    // the direct leg between memory-bound kernels, as in the RL loop: [stream, stream, direct] x 60, every
+    // direct launch timed on its own
+    Dim0DirectParams p;
+    p.in = in; p.out = out; p.taps = taps; p.d0 = d0; p.k = 31; p.kd = 32; p.h = 15; p.plane = plane; p.stagger = 64;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int nstream = 0; nstream <= 3; ++nstream) {
+      float sum = 0, mx = 0, last = 0;
+      for (int i = 0; i < 60; ++i) {
+        for (int k = 0; k < nstream; ++k)
+          hipLaunchKernelGGL(k_stream, dim3(256 * 16), dim3(256), 0, 0, (const float4*)in, (float4*)out, n / 2);
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kd_dim0<31>, dim3((unsigned)(plane / 256)), dim3(256), 0, 0, p);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 20) { sum += ms; mx = ms > mx ? ms : mx; }
+        last = ms;
+      }
+      std::printf("direct leg (K = 31) behind %d streaming kernel(s) of 0.2 ms: mean %.3f ms, max %.3f, last %.3f\n", nstream,
+                  sum / 40, mx, last);
     }
   }
   run<31, 4, 1>(in, out, taps, d0, plane, 1, hin, htaps, true);

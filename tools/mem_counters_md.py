@@ -11,6 +11,7 @@ import rocpd_stats
 
 KERNELS = [("kx_rows_r2c<256>", "rows_r2c", 2.0), ("kx_strided<512, 0>", "axis1_fwd", 2.0),
            ("kx_strided<512, 1>", "axis1_inv", 2.0), ("kx_strided<512, 2>", "axis0_fused", 3.0),
+           ("kd_dim0<31, 4>", "axis0_direct", 2.06),
            ("kw_rows<2, 1>", "rows_fused_div", 3.0), ("kw_rows<2, 2>", "rows_fused_upd", 5.0)]
 
 

@@ -406,7 +406,7 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t 
 }
 
 void launch_dim0_direct(const Dim0DirectParams& p, stream_t) {
-  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out ||
+  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 0 || p.plane + p.plane2 < 1 || (p.plane > 0 && p.in == p.out) ||
       p.plane2 < 0 || (p.plane2 > 0 && (!p.in2 || !p.out2 || !p.taps2 || p.in2 == p.out2)))
     throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
   switch (mvn_dim0_taps_template(p.k)) {

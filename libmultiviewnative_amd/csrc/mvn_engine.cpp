@@ -831,10 +831,10 @@ void Engine::ensure_work2() {
   if (plan_->nyq_bytes()) work2_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
 }
 
-// the dim0 leg with the direct form of kernel i: in -> out (never in place), main array and Nyquist plane in
-// ONE launch on the engine's stream
+// the dim0 leg with the direct form of kernel i: in -> out (never in place).  sn == stream_: main array and
+// Nyquist plane in ONE launch on the engine's stream; otherwise the Nyquist plane as a launch of its own on sn
 void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out,
-                       cfloat* out_nyq, Profiler* prof) {
+                       cfloat* out_nyq, Profiler* prof, be::stream_t sn) {
   const Layout& L = plan_->L;
   Dim0DirectParams p;
   p.in = in;
@@ -851,6 +851,12 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   p.taps2 = L.even ? s.taps_nyq[i] : nullptr;
   p.plane2 = L.even ? L.d1 : 0;
   p.seg2 = 16;
+  if (sn != stream_ && L.even) {
+    Dim0DirectParams q = p;
+    q.plane = 0;  // the Nyquist plane alone, in pieces of 16 output planes
+    be::launch_dim0_direct(q, sn);
+    p.plane2 = 0;
+  }
   ProfScope ps(prof, KK_AXIS0_DIRECT, stream_);
   be::launch_dim0_direct(p, stream_);
 }
@@ -864,16 +870,22 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
   }
   const bool use_side = side && side->s && P.L.even;
   be::stream_t sn = use_side ? side->s : stream_;
-  // the dim1 passes of the Nyquist plane ride on the side stream beside those of the main array; the dim0 leg
-  // takes both in one launch on stream_, so the side stream joins before it and forks again behind it
+  // MVN_D0_NYQ_SIDE=1: the Nyquist plane's whole chain (dim1, dim0 leg, dim1) on the side stream, one fork
+  // and one join per convolution; default: its dim0 leg rides in the main launch, the side stream joins
+  // before it and forks again behind it
+  static const bool nyq_side = env_int("MVN_D0_NYQ_SIDE", 0) != 0;
   if (use_side) side->fork_from(stream_);  // the plane was written by the last-axis pass just enqueued on stream_
   P.axis1(MVN_ST_FWD, (cfloat*)work_, work_nyq_, stream_, prof, sn);
-  if (use_side) side->join_into(stream_);
   ensure_work2();
-  dim0_conv(s, i, (const cfloat*)work_, work_nyq_, (cfloat*)work2_, work2_nyq_, prof);
+  if (use_side && nyq_side) {
+    dim0_conv(s, i, (const cfloat*)work_, work_nyq_, (cfloat*)work2_, work2_nyq_, prof, sn);
+  } else {
+    if (use_side) side->join_into(stream_);
+    dim0_conv(s, i, (const cfloat*)work_, work_nyq_, (cfloat*)work2_, work2_nyq_, prof, stream_);
+    if (use_side) side->fork_from(stream_);
+  }
   std::swap(work_, work2_);
   std::swap(work_nyq_, work2_nyq_);
-  if (use_side) side->fork_from(stream_);
   P.axis1(MVN_ST_INV, (cfloat*)work_, work_nyq_, stream_, prof, sn);
   if (use_side) side->join_into(stream_);  // the next last-axis pass on stream_ reads the plane
 }
@@ -1242,7 +1254,7 @@ void Engine::compute_delta_head(double lambda, float min_value) {
     if (s.tap_k[0]) {
       // (the shared spectrum of psi may still be in the making on the side stream: v == 0)
       if (use_side && v == 0) side_.join_into(stream_);
-      dim0_conv(s, 0, (const cfloat*)psi_spec_, psi_spec_nyq_, (cfloat*)work_, work_nyq_, prof);
+      dim0_conv(s, 0, (const cfloat*)psi_spec_, psi_spec_nyq_, (cfloat*)work_, work_nyq_, prof, stream_);
       if (use_side) side_.fork_from(stream_);
     } else {
       if (use_side) side_.fork_from(stream_);

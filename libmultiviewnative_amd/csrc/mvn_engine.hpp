@@ -319,7 +319,7 @@ class Engine {
   // dim1 forward -> dim0 leg (direct or fused FFT) -> dim1 inverse on the work volume, with kernel i of s
   void middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side);
   void dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out, cfloat* out_nyq,
-                 Profiler* prof);
+                 Profiler* prof, be::stream_t sn);
   void ensure_work2();
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;

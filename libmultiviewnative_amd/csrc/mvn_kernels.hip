@@ -732,10 +732,10 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
 }
 
 void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
-  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 1 || p.in == p.out ||
+  if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 0 || p.plane + p.plane2 < 1 || (p.plane > 0 && p.in == p.out) ||
       p.plane2 < 0 || (p.plane2 > 0 && (!p.in2 || !p.out2 || !p.taps2 || p.in2 == p.out2)))
     throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
-  check_aligned16(p.in, "input");  // (8-byte accesses; the volumes are 16-byte aligned anyway)
+  if (p.plane > 0) check_aligned16(p.in, "input");  // (8-byte accesses; the volumes are 16-byte aligned anyway)
   const long nblocks = (mvn_dim0_items(p) + 255) / 256;
   if (nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
   switch (mvn_dim0_taps_template(p.k)) {

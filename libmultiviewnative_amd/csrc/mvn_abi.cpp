@@ -362,6 +362,14 @@ static void deconvolve_call(imageType* psi, const workspace& input, int device, 
       t0 = t1;
     };
     eng.reserve_views();
+    {
+      // the loop starts before the last view has been staged: tell it now whether every kernel of the call
+      // will be held in the direct dim0 form (then the Nyquist bins ride in the DC column, mvn_dim0_direct.hpp)
+      bool all = true;
+      for (int v = 0; v < V && all; ++v)
+        all = eng.would_be_direct(input.data_[v].kernel1_dims_) && eng.would_be_direct(input.data_[v].kernel2_dims_);
+      eng.set_all_direct_hint(all);
+    }
     lap("allocate view buffers");
     std::unique_lock<std::mutex> pcie(upload_mutex(dev));  // handed to the uploader thread's scope below
     eng.set_psi(psi);

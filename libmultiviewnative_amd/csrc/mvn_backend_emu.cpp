@@ -409,6 +409,19 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t) {
   if (!mvn_dim0_direct_possible(p.k, p.d0) || p.kd < p.k + 1 || p.h != p.k / 2 || p.plane < 0 || p.plane + p.plane2 < 1 || (p.plane > 0 && p.in == p.out) ||
       p.plane2 < 0 || (p.plane2 > 0 && (!p.in2 || !p.out2 || !p.taps2 || p.in2 == p.out2)))
     throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
+  if (p.packed) {
+    if (!p.inv1 || !p.taps2 || (long)p.C * p.d1 != p.plane)
+      throw std::invalid_argument("mvn: packed direct dim0 convolution needs the dim1 tables and the Nyquist taps");
+#pragma omp parallel
+    {
+      std::vector<cfloat> lds(2 * (size_t)p.d0 + 2 * (size_t)p.k);
+#pragma omp for schedule(static)
+      for (int pair = 0; pair < mvn_dim0_pairs(p.d1); ++pair) {
+        for (int t = 0; t < 256; ++t) mvn_dim0_dc_load(p, pair, lds.data(), t, 256);
+        for (int t = 0; t < 256; ++t) mvn_dim0_dc_compute(p, pair, lds.data(), t, 256);
+      }
+    }
+  }
   switch (mvn_dim0_taps_template(p.k)) {
 #define X(K)                                                                        \
   case K: {                                                                         \

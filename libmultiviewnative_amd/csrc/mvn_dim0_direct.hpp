@@ -46,7 +46,78 @@ struct Dim0DirectParams {
   long plane2;
   int seg2;  // the second set's columns are cut into pieces of seg2 output planes, one work item each: a column
              // walked by ONE work item takes as long as the whole launch, and this set has only plane2 of them
+  // Packed Nyquist (RowsParams::nyq_packed): column 0 of the main array holds DC + i Nyquist of every row, both
+  // real before the dim1 transform, so after it  P[k1] = X0[k1] + i XH[k1]  with X0, XH Hermitian in k1.  The
+  // two need different taps (taps at column 0, taps2): workgroups beyond the main ones take one pair
+  // (k1, -k1) of column 0 each and compute, with U = (T0 + TH) / 2, V = (T0 - TH) / 2 at k1,
+  //     out[k1] = sum_j U_j a_j + V_j conj(b_j),   out[-k1] = conj( sum_j U_j conj(b_j) + V_j a_j )
+  // (a = P[k1], b = P[-k1] along dim0).  The main work items leave column 0 alone.  No Nyquist plane, no
+  // launches of its own for it, no second stream.
+  int packed;
+  int C, d1;        // bins per row, rows per plane (plane = d1 * C)
+  const int* inv1;  // inv1[k1] = row that holds bin k1 along dim1 (position order, AxisPlan::inv)
 };
+
+#define MVN_D0_PF 4         // planes requested ahead
+#define MVN_D0_MAX_TAPS 33  // largest instantiated K
+
+// acc + a * w (complex): two packed fused multiply-adds on the device
+MVN_HD cfloat mvn_cmac(cfloat acc, cfloat a, cfloat w) {
+#if defined(MVN_PACKED)
+  cfloat t, r;
+  MVN_PK3(t, "v_pk_fma_f32", a, w, acc, "op_sel_hi:[0,1,1]");                                // (a.x w.x, a.x w.y) + acc
+  MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]");  // + (-a.y w.y, a.y w.x)
+  return r;
+#else
+  return cmake(acc.x + a.x * w.x - a.y * w.y, acc.y + a.x * w.y + a.y * w.x);
+#endif
+}
+
+// pairs (k1, -k1) of the packed DC column
+inline int mvn_dim0_pairs(int d1) { return d1 / 2 + 1; }
+
+// One pair per workgroup, two phases around a workgroup barrier.  lds: 2 * d0 + 2 * k cfloats.
+MVN_HD void mvn_dim0_dc_load(const Dim0DirectParams& P, int pair, cfloat* lds, int tid, int nthreads) {
+  const int k1 = pair, k1m = (P.d1 - pair) % P.d1;
+  const long ra = (long)P.inv1[k1] * P.C, rb = (long)P.inv1[k1m] * P.C;
+  cfloat* a = lds;
+  cfloat* b = lds + P.d0;
+  cfloat* U = lds + 2 * (long)P.d0;
+  cfloat* V = U + P.k;
+  for (int z = tid; z < P.d0; z += nthreads) {
+    a[z] = P.in[(long)z * P.plane + ra];
+    b[z] = P.in[(long)z * P.plane + rb];
+  }
+  for (int j = tid; j < P.k; j += nthreads) {
+    int p = j - P.h;
+    p = p < 0 ? p + P.kd : p;
+    const cfloat t0 = P.taps[(long)p * P.plane + ra];
+    const cfloat th = P.taps2[(long)p * P.d1 + P.inv1[k1]];
+    U[j] = cmake(0.5f * (t0.x + th.x), 0.5f * (t0.y + th.y));
+    V[j] = cmake(0.5f * (t0.x - th.x), 0.5f * (t0.y - th.y));
+  }
+}
+MVN_HD void mvn_dim0_dc_compute(const Dim0DirectParams& P, int pair, const cfloat* lds, int tid, int nthreads) {
+  const int k1 = pair, k1m = (P.d1 - pair) % P.d1;
+  const long ra = (long)P.inv1[k1] * P.C, rb = (long)P.inv1[k1m] * P.C;
+  const cfloat* a = lds;
+  const cfloat* b = lds + P.d0;
+  const cfloat* U = lds + 2 * (long)P.d0;
+  const cfloat* V = U + P.k;
+  for (int z = tid; z < P.d0; z += nthreads) {
+    cfloat s1 = cmake(0.f, 0.f), s2 = cmake(0.f, 0.f);
+    int zi = z + P.h;
+    zi = zi >= P.d0 ? zi - P.d0 : zi;
+    for (int j = 0; j < P.k; ++j) {
+      const cfloat av = a[zi], bc = cconj(b[zi]);
+      s1 = mvn_cmac(mvn_cmac(s1, av, U[j]), bc, V[j]);
+      s2 = mvn_cmac(mvn_cmac(s2, bc, U[j]), av, V[j]);
+      zi = zi == 0 ? P.d0 - 1 : zi - 1;
+    }
+    P.out[(long)z * P.plane + ra] = s1;
+    if (rb != ra) P.out[(long)z * P.plane + rb] = cconj(s2);
+  }
+}
 
 // work item `g` of a launch: the arrays it belongs to, the bin it owns there and the output planes
 // [z0, z0 + nout) it produces (cyclically)
@@ -54,12 +125,13 @@ MVN_HD bool mvn_dim0_select(const Dim0DirectParams& P, long g, int wg_start, Dim
                             int& nout) {
   Q = P;
   if (g < P.plane) {
+    if (P.packed && g % P.C == 0) return false;  // the packed DC column belongs to the pair workgroups
     b = g;
     z0 = wg_start;
     nout = P.d0;
     return true;
   }
-  if (P.plane2 <= 0) return false;
+  if (P.plane2 <= 0 || P.packed) return false;
   const long g2 = g - P.plane;
   const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
   const long piece = g2 / P.plane2;
@@ -75,23 +147,9 @@ MVN_HD bool mvn_dim0_select(const Dim0DirectParams& P, long g, int wg_start, Dim
 }
 // work items of a launch
 inline long mvn_dim0_items(const Dim0DirectParams& P) {
+  if (P.packed) return P.plane;  // + mvn_dim0_pairs(P.d1) workgroups, see the launchers
   const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
   return P.plane + (P.plane2 > 0 ? P.plane2 * ((P.d0 + seg - 1) / seg) : 0);
-}
-
-#define MVN_D0_PF 4         // planes requested ahead
-#define MVN_D0_MAX_TAPS 33  // largest instantiated K
-
-// acc + a * w (complex): two packed fused multiply-adds on the device
-MVN_HD cfloat mvn_cmac(cfloat acc, cfloat a, cfloat w) {
-#if defined(MVN_PACKED)
-  cfloat t, r;
-  MVN_PK3(t, "v_pk_fma_f32", a, w, acc, "op_sel_hi:[0,1,1]");                                // (a.x w.x, a.x w.y) + acc
-  MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]");  // + (-a.y w.y, a.y w.x)
-  return r;
-#else
-  return cmake(acc.x + a.x * w.x - a.y * w.y, acc.y + a.x * w.y + a.y * w.x);
-#endif
 }
 
 template <int K, int PF>

@@ -280,6 +280,7 @@ void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::st
   p.in_real = in_real;
   p.out_cplx = out;
   p.out_nyq = out_nyq;
+  p.nyq_packed = (L.even && !out_nyq) ? 1 : 0;  // no Nyquist plane given: DC + i Nyquist in column 0
   ProfScope ps(prof, KK_ROWS_R2C, s);
   if (fx_rows) {
     p.fixed = 1;
@@ -321,6 +322,7 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   p.Cmul = mvn_fastdiv_mul((unsigned)L.C);
   p.in_cplx = in;
   p.in_nyq = in_nyq;
+  p.nyq_packed = (L.even && !in_nyq) ? 1 : 0;
   p.out_real = out_real;
   p.epi = epi;
   ProfScope ps(prof, KK_ROWS_C2R, s);
@@ -350,6 +352,7 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, 
   p.in_nyq = nyq;
   p.out_cplx = data;
   p.out_nyq = nyq;
+  p.nyq_packed = nyq ? 0 : 1;
   p.epi = epi;
   ProfScope ps(prof, epi.mode == MVN_EPI_UPDATE ? KK_ROWS_FUSED_UPD : KK_ROWS_FUSED, s);
   if (fx_rows) {
@@ -427,7 +430,7 @@ void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler
     ProfScope ps(prof, mode == MVN_ST_FWD ? KK_AXIS1_FWD : KK_AXIS1_INV, s);
     be::launch_strided(mode, p, (long)nz * p.tiles_per_outer, g.threads, g.lds_bytes, s);
   }
-  if (L.even) {
+  if (L.even && nyq) {  // (no plane: the Nyquist bins are packed into column 0 of the main array)
     // Nyquist plane [d0][d1]: lines along d1 are contiguous, neighbouring lines d1 apart
     StridedParams p = make_strided(ax1, g_nyq1, nyq, nullptr, 0, 1, L.d1, nz);
     p.is_nyq = 1;
@@ -611,6 +614,11 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
   direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
   d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
+  // Opt-in: measured at 512^3 x 6 views x 31^3 PSFs the packed layout saves the Nyquist plane's 24 launches and
+  // every cross-queue wait of an iteration and is nevertheless 2 - 4 % SLOWER (13.1 - 13.4 against 12.85 ms:
+  // with the gaps gone the clock-sensitive passes - fused update +6 %, fused divide +3 %, the direct leg +6 % -
+  // lose more than the launches cost; profiles/r03_ab_packed_nyquist.txt)
+  packed_allowed_ = env_int("MVN_NYQ_PACKED", 0) != 0;
   for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);
 }
@@ -831,12 +839,14 @@ void Engine::ensure_work2() {
   if (plan_->nyq_bytes()) work2_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
 }
 
-// the dim0 leg with the direct form of kernel i: in -> out (never in place).  sn == stream_: main array and
-// Nyquist plane in ONE launch on the engine's stream; otherwise the Nyquist plane as a launch of its own on sn
+// the dim0 leg with the direct form of kernel i: in -> out (never in place).  Packed layout: one launch, the
+// DC + i Nyquist column separated inside it.  Split layout: sn == stream_: main array and Nyquist plane in ONE
+// launch on the engine's stream; otherwise the Nyquist plane as a launch of its own on sn
 void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out,
                        cfloat* out_nyq, Profiler* prof, be::stream_t sn) {
   const Layout& L = plan_->L;
   Dim0DirectParams p;
+  std::memset(&p, 0, sizeof(p));
   p.in = in;
   p.out = out;
   p.taps = (const cfloat*)s.taps[i];
@@ -846,6 +856,16 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   p.h = s.tap_k[i] / 2;
   p.plane = (long)L.d1 * L.C;
   p.stagger = d0_stagger_;
+  p.C = L.C;
+  p.d1 = L.d1;
+  if (packed_) {
+    p.packed = 1;
+    p.taps2 = s.taps_nyq[i];
+    p.inv1 = plan_->ax1.view.inv;
+    ProfScope ps(prof, KK_AXIS0_DIRECT, stream_);
+    be::launch_dim0_direct(p, stream_);
+    return;
+  }
   p.in2 = L.even ? in_nyq : nullptr;
   p.out2 = L.even ? out_nyq : nullptr;
   p.taps2 = L.even ? s.taps_nyq[i] : nullptr;
@@ -861,8 +881,34 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   be::launch_dim0_direct(p, stream_);
 }
 
+// every view's two kernels are held in the direct form: the Nyquist bins can ride in the DC column
+bool Engine::all_direct() const {
+  if (views_.empty()) return false;
+  for (size_t v = 0; v < views_.size(); ++v)
+    if (!views_[v].set || !views_[v].tap_k[0] || !views_[v].tap_k[1]) return false;
+  return true;
+}
+
+void Engine::decide_layout() {
+  const bool want = packed_allowed_ && plan_->L.even && plan_->nyq_bytes() > 0;
+  packed_ = want && (pipelined_ ? packed_hint_ : all_direct());
+}
+
+bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
+
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {
   const Plan3D& P = *plan_;
+  if (packed_) {
+    // no Nyquist plane, no second stream: three launches on stream_
+    if (!s.tap_k[i]) throw std::logic_error("mvn: packed Nyquist layout with a kernel that is not in the direct form");
+    P.axis1(MVN_ST_FWD, (cfloat*)work_, nullptr, stream_, prof, stream_);
+    ensure_work2();
+    dim0_conv(s, i, (const cfloat*)work_, nullptr, (cfloat*)work2_, nullptr, prof, stream_);
+    std::swap(work_, work2_);
+    std::swap(work_nyq_, work2_nyq_);
+    P.axis1(MVN_ST_INV, (cfloat*)work_, nullptr, stream_, prof, stream_);
+    return;
+  }
   if (!s.tap_k[i]) {
     P.middle_passes((cfloat*)work_, work_nyq_, (const cfloat*)(i == 0 ? s.spec1 : s.spec2), i == 0 ? s.nyq1 : s.nyq2,
                     stream_, prof, side, spec_tiled_);
@@ -1061,23 +1107,23 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
   SideStream* side = (no_side || P.main_bytes() <= side_min_bytes) ? nullptr : &side_;
   // (work_ / work_nyq_ are re-read after every middle(): the direct dim0 leg swaps the two work volumes)
-  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, (cfloat*)work_, work_nyq_, stream_, prof);
+  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, (cfloat*)work_, wn(), stream_, prof);
   work_has_psi_spectrum_ = false;
   middle(s, 0, prof, side);
   // view / blurred, handed to convolution 2 as its last-axis spectrum
   if (fuse) {
-    P.rows_c2r_r2c((cfloat*)work_, work_nyq_, e1, stream_, prof);
+    P.rows_c2r_r2c((cfloat*)work_, wn(), e1, stream_, prof);
   } else {
-    P.rows_c2r((const cfloat*)work_, work_nyq_, work_, e1, stream_, prof);
-    P.rows_r2c(work_, (cfloat*)work_, work_nyq_, stream_, prof);
+    P.rows_c2r((const cfloat*)work_, wn(), work_, e1, stream_, prof);
+    P.rows_r2c(work_, (cfloat*)work_, wn(), stream_, prof);
   }
   // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
   middle(s, 1, prof, side);
   if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
-    P.rows_c2r_r2c((cfloat*)work_, work_nyq_, e2, stream_, prof);
+    P.rows_c2r_r2c((cfloat*)work_, wn(), e2, stream_, prof);
     work_has_psi_spectrum_ = true;
   } else {
-    P.rows_c2r((const cfloat*)work_, work_nyq_, psi_, e2, stream_, prof);
+    P.rows_c2r((const cfloat*)work_, wn(), psi_, e2, stream_, prof);
   }
 }
 
@@ -1092,6 +1138,7 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
   be::set_device(device_);
   work_has_psi_spectrum_ = false;  // psi may have been replaced since the last call
   psi_spec_valid_ = false;
+  decide_layout();
   const int V = (int)views_.size();
   static const bool graphs_on = env_int("MVN_GRAPH", 0) != 0 && be::graphs_supported();
   static const size_t graph_max_bytes = (size_t)env_int("MVN_GRAPH_MAX_MB", 160) << 20;
@@ -1206,6 +1253,11 @@ void Engine::compute_delta_head(double lambda, float min_value) {
   work_has_psi_spectrum_ = false;
   const int V = (int)views_.size();
   if (V == 0) return;  // a rank without views contributes a zero correction (compute_delta_chunk)
+  {
+    const bool was = packed_;
+    decide_layout();
+    if (was != packed_) psi_spec_valid_ = false;  // the chunk-fed spectrum of psi is in the other layout
+  }
   const Plan3D& P = *plan_;
   // event pairs around every launch cost ~3 % of a sweep: sample like iterate() does
   const int every = prof_.sample_every > 0 ? prof_.sample_every : 1;
@@ -1219,12 +1271,12 @@ void Engine::compute_delta_head(double lambda, float min_value) {
   const bool fuse = P.can_fuse_rows() && !no_fuse;
   static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;
   static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
-  const bool use_side = !no_side && side_.s && P.L.even && P.main_bytes() > side_min_bytes;
+  const bool use_side = !no_side && side_.s && P.L.even && P.main_bytes() > side_min_bytes && !packed_;
   be::stream_t sn = use_side ? side_.s : stream_;
   if (!psi_spec_valid_) {  // else: left there chunk by chunk by apply_delta_chunk(.., feed_next)
-    P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof);
+    P.rows_r2c(psi_, (cfloat*)psi_spec_, pn(), stream_, prof);
     if (use_side) side_.fork_from(stream_);
-    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, prof, sn);
+    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, pn(), stream_, prof, sn);
   }
   psi_spec_valid_ = false;  // consumed by this step; psi changes when the correction is applied
   for (int v = 0; v < V; ++v) {
@@ -1254,24 +1306,24 @@ void Engine::compute_delta_head(double lambda, float min_value) {
     if (s.tap_k[0]) {
       // (the shared spectrum of psi may still be in the making on the side stream: v == 0)
       if (use_side && v == 0) side_.join_into(stream_);
-      dim0_conv(s, 0, (const cfloat*)psi_spec_, psi_spec_nyq_, (cfloat*)work_, work_nyq_, prof, stream_);
+      dim0_conv(s, 0, (const cfloat*)psi_spec_, pn(), (cfloat*)work_, wn(), prof, stream_);
       if (use_side) side_.fork_from(stream_);
     } else {
       if (use_side) side_.fork_from(stream_);
-      P.axis0(MVN_ST_FWD_MUL_INV, (cfloat*)work_, work_nyq_, (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
-              (const cfloat*)psi_spec_, psi_spec_nyq_, spec_tiled_);
+      P.axis0(MVN_ST_FWD_MUL_INV, (cfloat*)work_, wn(), (const cfloat*)s.spec1, s.nyq1, stream_, prof, sn,
+              (const cfloat*)psi_spec_, pn(), spec_tiled_);
     }
-    P.axis1(MVN_ST_INV, (cfloat*)work_, work_nyq_, stream_, prof, sn);
+    P.axis1(MVN_ST_INV, (cfloat*)work_, wn(), stream_, prof, sn);
     if (use_side) side_.join_into(stream_);
     if (fuse) {
-      P.rows_c2r_r2c((cfloat*)work_, work_nyq_, e1, stream_, prof);
+      P.rows_c2r_r2c((cfloat*)work_, wn(), e1, stream_, prof);
     } else {
-      P.rows_c2r((const cfloat*)work_, work_nyq_, work_, e1, stream_, prof);
-      P.rows_r2c(work_, (cfloat*)work_, work_nyq_, stream_, prof);
+      P.rows_c2r((const cfloat*)work_, wn(), work_, e1, stream_, prof);
+      P.rows_r2c(work_, (cfloat*)work_, wn(), stream_, prof);
     }
     middle(s, 1, prof, use_side ? &side_ : nullptr);
     if (v + 1 < V) {
-      P.rows_c2r((const cfloat*)work_, work_nyq_, psi_, e2, stream_, prof);
+      P.rows_c2r((const cfloat*)work_, wn(), psi_, e2, stream_, prof);
     } else {  // the last view's final pass is launched chunk by chunk (compute_delta_chunk)
       tail_epi_ = e2;
       tail_prof_ = prof;
@@ -1292,7 +1344,7 @@ void Engine::compute_delta_chunk(int c, int n) {
     return;
   }
   if (!tail_pending_) throw std::logic_error("mvn: compute_delta_chunk without compute_delta_head");
-  plan_->rows_c2r((const cfloat*)work_, work_nyq_, psi_, tail_epi_, stream_, c == 0 ? tail_prof_ : nullptr,
+  plan_->rows_c2r((const cfloat*)work_, wn(), psi_, tail_epi_, stream_, c == 0 ? tail_prof_ : nullptr,
                   (long)z0 * L.d1, (long)nz * L.d1);
   if (c == n - 1) tail_pending_ = false;
 }
@@ -1316,9 +1368,9 @@ void Engine::apply_delta_chunk(int c, int n, bool feed_next) {
       psi_spec_ = (float*)be::dmalloc(P.main_bytes());
       if (P.nyq_bytes()) psi_spec_nyq_ = (cfloat*)be::dmalloc(P.nyq_bytes());
     }
-    P.rows_r2c(psi_, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, nullptr, (long)z0 * P.L.d1,
+    P.rows_r2c(psi_, (cfloat*)psi_spec_, pn(), stream_, nullptr, (long)z0 * P.L.d1,
                (long)nz * P.L.d1);
-    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, psi_spec_nyq_, stream_, nullptr, stream_, z0, nz);
+    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, pn(), stream_, nullptr, stream_, z0, nz);
     if (++fed_ == n) {  // every plane of the spectrum belongs to the new psi
       psi_spec_valid_ = true;
       fed_ = 0;

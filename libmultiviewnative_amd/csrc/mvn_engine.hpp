@@ -281,6 +281,10 @@ class Engine {
   void set_embedding(const int dims[3], const int off[3]);
   // quotient 0 wherever the view is exactly 0 (see EpilogueParams::guard_zero_view)
   void set_quotient_guard(bool on) { quotient_guard_ = on; }
+  // pipelined ABI call: will a kernel of these extents be held in the direct dim0 form? / every kernel of the
+  // call will (so the loop may start on the packed Nyquist layout before the last view has been staged)
+  bool would_be_direct(const int* kdims);
+  void set_all_direct_hint(bool all) { packed_hint_ = all; }
   // a cached engine starts every ABI call from a clean per-call state
   void begin_call() {
     pipelined_ = false;
@@ -321,6 +325,14 @@ class Engine {
   void dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out, cfloat* out_nyq,
                  Profiler* prof, be::stream_t sn);
   void ensure_work2();
+  // Nyquist layout of the spectra between the last-axis passes of one call (mvn_dim0_direct.hpp, RowsParams::
+  // nyq_packed): packed into the DC column when every kernel of every view is in the direct form, else the
+  // separate plane.  Decided when a loop starts; a pipelined ABI call decides from the kernel extents up front.
+  bool all_direct() const;
+  void decide_layout();
+  cfloat* wn() const { return packed_ ? nullptr : work_nyq_; }
+  cfloat* pn() const { return packed_ ? nullptr : psi_spec_nyq_; }
+  bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;
   int direct_max_taps_ = MVN_D0_MAX_TAPS;

@@ -1192,8 +1192,12 @@ MVN_HD void fx_r2c_post(const RowsParams& P, long r0, cfloat* buf, const cfloat*
     const cfloat zk = *pa;
     const cfloat zm = *pb;
     if (k == 0) {
-      *pa = cmake(zk.x + zk.y, 0.f);                       // DC
-      P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);       // Nyquist, kept in its own plane
+      if (P.nyq_packed) {
+        *pa = cmake(zk.x + zk.y, zk.x - zk.y);             // DC + i Nyquist (RowsParams::nyq_packed)
+      } else {
+        *pa = cmake(zk.x + zk.y, 0.f);                     // DC
+        P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);     // Nyquist, kept in its own plane
+      }
       *pb = cconj(zm);                                     // bin H/2 pairs with itself
     } else {
       const cfloat E = cscale(cadd_c(zk, zm), 0.5f);
@@ -1310,7 +1314,7 @@ MVN_HD void fx_c2r_pre(const RowsParams& P, long r0, cfloat* buf, const cfloat* 
     const cfloat xm = *pb;
     if (k == 0) {
       // imaginary parts of the DC and Nyquist bins are ignored, as FFTW's c2r does
-      const float xh = P.in_nyq[r0 + rho].x;
+      const float xh = P.nyq_packed ? xk.y : P.in_nyq[r0 + rho].x;
       *pa = cmake(xk.x + xh, xk.x - xh);
       *pb = cmake(2.f * xm.x, -2.f * xm.y);  // bin H/2 pairs with itself: Z = 2 conj(X)
     } else {

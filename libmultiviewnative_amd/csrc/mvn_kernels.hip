@@ -143,7 +143,15 @@ __global__ void __launch_bounds__((FxSplitCfg<N>::NT)) kx_strided_split(const St
 
 // direct dim0 convolution (mvn_dim0_direct.hpp): one bin per work item, all of dim0
 template <int K, int PF = MVN_D0_PF>
-__global__ void __launch_bounds__(256) kd_dim0(const Dim0DirectParams p) {
+__global__ void __launch_bounds__(256) kd_dim0(const Dim0DirectParams p, unsigned main_blocks) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  if (blockIdx.x >= main_blocks) {  // packed Nyquist: one (k1, -k1) pair of the DC column per workgroup
+    const int pair = (int)(blockIdx.x - main_blocks);
+    mvn_dim0_dc_load(p, pair, (cfloat*)mvn_smem, (int)threadIdx.x, 256);
+    __syncthreads();
+    mvn_dim0_dc_compute(p, pair, (const cfloat*)mvn_smem, (int)threadIdx.x, 256);
+    return;
+  }
   // workgroups start their cyclic walk along dim0 at different planes (p.stagger): all of them on one
   // plane at a time keep the whole chip on 1 MB in and 1 MB out
   const int z0 = p.stagger > 0 ? (int)(((long)blockIdx.x * p.stagger) % p.d0) : 0;
@@ -736,10 +744,19 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
       p.plane2 < 0 || (p.plane2 > 0 && (!p.in2 || !p.out2 || !p.taps2 || p.in2 == p.out2)))
     throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
   if (p.plane > 0) check_aligned16(p.in, "input");  // (8-byte accesses; the volumes are 16-byte aligned anyway)
-  const long nblocks = (mvn_dim0_items(p) + 255) / 256;
+  const long main_blocks = (mvn_dim0_items(p) + 255) / 256;
+  long nblocks = main_blocks;
+  size_t lds = 0;
+  if (p.packed) {
+    if (!p.inv1 || !p.taps2 || p.C < 1 || p.d1 < 1 || (long)p.C * p.d1 != p.plane)
+      throw std::invalid_argument("mvn: packed direct dim0 convolution needs the dim1 tables and the Nyquist taps");
+    nblocks += mvn_dim0_pairs(p.d1);
+    lds = sizeof(cfloat) * (2 * (size_t)p.d0 + 2 * (size_t)p.k);
+    if (lds > 64 * 1024) throw std::invalid_argument("mvn: dim0 too long for the packed DC column");
+  }
   if (nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
   switch (mvn_dim0_taps_template(p.k)) {
-#define X(K) case K: hipLaunchKernelGGL(kd_dim0<K>, dim3((unsigned)nblocks), dim3(256), 0, hs(s), p); break;
+#define X(K) case K: hipLaunchKernelGGL(kd_dim0<K>, dim3((unsigned)nblocks), dim3(256), lds, hs(s), p, (unsigned)main_blocks); break;
     MVN_D0_TAP_COUNTS(X)
 #undef X
     default: throw std::invalid_argument("mvn: no direct dim0 kernel for this tap count");

@@ -248,6 +248,10 @@ struct RowsParams {
   const cfloat* in_nyq;
   float* out_real;
   EpilogueParams epi;
+  // 1: the Nyquist bin of a row (real, like its DC bin) is carried in the IMAGINARY part of the DC bin and
+  // there is no Nyquist plane (in_nyq / out_nyq unused): the dim1 passes then transform DC + i Nyquist as one
+  // complex column and the direct dim0 leg separates the two by the k1 <-> -k1 symmetry (mvn_dim0_direct.hpp)
+  int nyq_packed;
 };
 
 // forward stages + real<->complex step + store of a tile that already sits in LDS as the packed
@@ -264,8 +268,12 @@ MVN_HD void rows_r2c_even_tail(const RowsParams& P, long r0, cfloat*& buf, cfloa
     const int pk = P.ax.inv[k], pm = P.ax.inv[m];
     const cfloat zk = buf[pk * TP + rho];
     if (k == 0) {
-      buf[pk * TP + rho] = cmake(zk.x + zk.y, 0.f);
-      if (r0 + rho < P.rows) P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);
+      if (P.nyq_packed) {
+        buf[pk * TP + rho] = cmake(zk.x + zk.y, zk.x - zk.y);
+      } else {
+        buf[pk * TP + rho] = cmake(zk.x + zk.y, 0.f);
+        if (r0 + rho < P.rows) P.out_nyq[r0 + rho] = cmake(zk.x - zk.y, 0.f);
+      }
     } else {
       const cfloat zm = buf[pm * TP + rho];
       const cfloat E = cmake(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
@@ -376,7 +384,10 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
     if (k == 0) {
       // imaginary parts of the DC and Nyquist bins are ignored, as FFTW's c2r does
       float xh = 0.f;
-      if (r0 + rho < P.rows) xh = P.in_nyq[r0 + rho].x;
+      if (P.nyq_packed)
+        xh = xk.y;
+      else if (r0 + rho < P.rows)
+        xh = P.in_nyq[r0 + rho].x;
       buf[pk * TP + rho] = cmake(xk.x + xh, xk.x - xh);
     } else {
       const cfloat xm = buf[pm * TP + rho];

@@ -256,7 +256,7 @@ MVN_HD void wr_phase_a(const RowsParams& P, long row, long next_row, cfloat* row
   wr_pw<EPI>(r, rows, t, pw);
   if (t == 0) {
     // imaginary parts of the DC and Nyquist bins are ignored, as FFTW's c2r does
-    const float xh = P.in_nyq[row].x;
+    const float xh = P.nyq_packed ? za[0].y : P.in_nyq[row].x;
     za[0] = cmake(za[0].x + xh, za[0].x - xh);
     wr_pre_pair(za[1], za[3], pw[0]);
     za[2] = cmake(2.f * za[2].x, -2.f * za[2].y);  // bin H/2 pairs with itself: Z = 2 conj(X)
@@ -389,8 +389,12 @@ MVN_HD void wr_phase_e(const RowsParams& P, long row, const cfloat* rows, const 
   wr_pw<EPI>(r, rows, t, pw);
   if (t == 0) {
     const cfloat z0 = za[0];
-    za[0] = cmake(z0.x + z0.y, 0.f);                      // DC
-    P.out_nyq[row] = cmake(z0.x - z0.y, 0.f);             // Nyquist, kept in its own plane
+    if (P.nyq_packed) {
+      za[0] = cmake(z0.x + z0.y, z0.x - z0.y);            // DC + i Nyquist (RowsParams::nyq_packed)
+    } else {
+      za[0] = cmake(z0.x + z0.y, 0.f);                    // DC
+      P.out_nyq[row] = cmake(z0.x - z0.y, 0.f);           // Nyquist, kept in its own plane
+    }
     wr_post_pair(za[1], za[3], pw[0]);
     za[2] = cconj(za[2]);                                 // bin H/2 pairs with itself
     wr_post_pair(zb[0], zb[3], pw[1]);

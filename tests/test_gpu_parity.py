@@ -1260,7 +1260,7 @@ print("direct child ok", os.environ.get("MVN_DIM0_DIRECT"), "%.2e" % worst)
 """
 
 
-@pytest.mark.parametrize("direct", ["1", "0"])
+@pytest.mark.parametrize("direct", ["1", "0", "1 packed"])
 def test_direct_dim0_leg_in_a_child_process(gpu, direct):
     # mvn_dim0_direct.hpp on the GPU: PSF depths 1 .. 33 (odd, even, the largest instantiated), d2 = 512
     # wave-row shapes and odd extents, sequential and simultaneous loops, against the oracle -- and the
@@ -1269,6 +1269,8 @@ def test_direct_dim0_leg_in_a_child_process(gpu, direct):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MVN_DIM0_DIRECT=direct, MVN_DIM0_DIRECT_MAX="33")
+    # "1": the default (separate Nyquist plane under the direct leg); "1 packed": MVN_NYQ_PACKED=1, the Nyquist
+    # bins packed into the DC column and separated inside the direct leg (no Nyquist launches, one stream)
+    env = dict(os.environ, MVN_DIM0_DIRECT=direct[0], MVN_DIM0_DIRECT_MAX="33", MVN_NYQ_PACKED="1" if "packed" in direct else "0")
     r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD, root], capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and "direct child ok " + direct in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.returncode == 0 and "direct child ok " + direct[0] in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -613,6 +613,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   // the whole iteration is 6.7 / 4.1 % faster than with the fused FFT pass at 15 / 31 planes
   direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
   direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
+  direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 98304);  // columns per plane, see direct_ok_for()
   d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
   // Opt-in: measured at 512^3 x 6 views x 31^3 PSFs the packed layout saves the Nyquist plane's 24 launches and
   // every cross-queue wait of an iteration and is nevertheless 2 - 4 % SLOWER (13.1 - 13.4 against 12.85 ms:
@@ -765,7 +766,9 @@ void Engine::make_spectrum(const float* d_kernel, const int* kdims, float scale,
 // deep enough for the kernel's window, and the small plan of the tap arrays transforms dims 1 and 2
 // exactly as the volume's plan does (same kernel family => same position order of the spectra).
 bool Engine::direct_form(const int* kdims) {
-  if (!direct_enabled_ || kdims[0] > direct_max_taps_ || !mvn_dim0_direct_possible(kdims[0], plan_->L.d0)) return false;
+  if (!direct_enabled_ || kdims[0] > direct_max_taps_ || !mvn_dim0_direct_possible(kdims[0], plan_->L.d0) ||
+      (long)plan_->L.d1 * plan_->L.C < direct_min_plane_)
+    return false;
   const int kd = ((kdims[0] + 1 + 15) / 16) * 16;
   const Plan3D* tp = taps_plan(kd);
   return tp->fx_rows == plan_->fx_rows && tp->fx_ax1 == plan_->fx_ax1 && tp->L.C == plan_->L.C &&
@@ -895,6 +898,17 @@ void Engine::decide_layout() {
 }
 
 bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
+
+// Is the direct dim0 leg the better one for PSFs of k0 planes on a (d0, d1, d2) volume?  Switches MVN_DIM0_DIRECT,
+// MVN_DIM0_DIRECT_MAX (deepest PSF, <= 33) and MVN_DIM0_DIRECT_MIN_PLANE: a work item walks a whole column, so
+// the leg needs enough columns (d1 * C bins per plane) to fill the chip - measured per view update with 15^3
+// PSFs (profiles/r03_shapes.txt): 256^3 (33 k columns) 0.371 against 0.302 ms with the fused FFT pass, 384^3
+// (74 k) 1.070 against 1.052, 512^3 (131 k) 2.14 against 2.32, 1024^3 17.4 against 19.9.
+bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
+  const long plane = (long)d1 * (d2 % 2 == 0 ? d2 / 2 : (d2 + 1) / 2);
+  return env_int("MVN_DIM0_DIRECT", 1) != 0 && k0 >= 1 && k0 <= env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS) &&
+         mvn_dim0_direct_possible(k0, d0) && plane >= (long)env_int("MVN_DIM0_DIRECT_MIN_PLANE", 98304);
+}
 
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {
   const Plan3D& P = *plan_;

@@ -284,6 +284,8 @@ class Engine {
   // pipelined ABI call: will a kernel of these extents be held in the direct dim0 form? / every kernel of the
   // call will (so the loop may start on the packed Nyquist layout before the last view has been staged)
   bool would_be_direct(const int* kdims);
+  // the direct dim0 leg is enabled and is the better leg for PSFs of this depth on a volume of these extents
+  static bool direct_ok_for(int k0, int d0, int d1, int d2);
   void set_all_direct_hint(bool all) { packed_hint_ = all; }
   // a cached engine starts every ABI call from a clean per-call state
   void begin_call() {
@@ -336,6 +338,7 @@ class Engine {
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;
   int direct_max_taps_ = MVN_D0_MAX_TAPS;
+  long direct_min_plane_ = 98304;
   std::map<int, std::unique_ptr<Plan3D>> taps_plans_;  // (kd, d1, d2) plans of the tap arrays, private to the engine
   // second work volume: the direct dim0 leg is out of place, work_ and work2_ swap roles after it
   float* work2_ = nullptr;

@@ -777,6 +777,7 @@ def test_direct_dim0_leg_vs_fft_leg_and_oracle(emu, monkeypatch, k0):
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (k0, 5, 3), seed=50 + k0)
     k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]  # an asymmetric second kernel of the same depth
     monkeypatch.setenv("MVN_DIM0_DIRECT_MAX", "33")
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")  # (by default the leg is for planes of >= 98304 bins)
     results = {}
     # "direct" / "staggered": Nyquist bins packed into the DC column (opt-in, every kernel is in the direct form);
     # "split": the separate Nyquist plane under the direct leg (the default)
@@ -814,6 +815,7 @@ def test_direct_dim0_leg_limits_and_nonfinite(emu, monkeypatch):
     # too deep a PSF / too shallow a volume fall back to the FFT leg; a non-finite voxel floods the
     # volume exactly as the FFT leg does (the update then clamps everything to minValue)
     monkeypatch.setenv("MVN_DIM0_DIRECT_MAX", "33")
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")
     emu.l.mvn_release_cached_engines()
     for shape, kshape in (((40, 10, 12), (35, 3, 3)), ((12, 10, 12), (9, 3, 3)), ((8, 6, 10), (3, 3, 3))):
         _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=7)
@@ -830,4 +832,52 @@ def test_direct_dim0_leg_limits_and_nonfinite(emu, monkeypatch):
     got = emu.gpu_deconvolve(psi_bad, h)
     ref = orc.cpu_deconvolve(psi_bad, h, 2)
     assert np.array_equal(got, ref, equal_nan=True) and np.isfinite(got).sum() >= got.size - 1  # all clamped; the voxel itself stays NaN
+    emu.l.mvn_release_cached_engines()
+
+
+def test_default_policy_keeps_dim0_exact_under_the_direct_leg(emu, monkeypatch):
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")
+    # zero_padd with FFT-friendly extents pads dim1 / dim2 to good sizes but leaves dim0 at the reference's exact
+    # image + kernel - 1 when every PSF is thin enough for the direct dim0 leg (no transform along dim0) and d1
+    # keeps whole last-axis tiles: 20 + 4 - 1 = 23 planes (not 24), 26 + 7 - 1 = 32, 30 + 3 - 1 = 32.  With the
+    # direct leg switched off the old rule applies (24 planes).
+    from ref_fixtures import expected_good_extent
+    shape = (20, 26, 30)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (4, 7, 3), seed=12)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    off = (1, 3, 1)  # (kernel - 1) / 2
+    sl = tuple(slice(o, o + s) for o, s in zip(off, shape))
+
+    def reference(ext):
+        def embed(x):
+            out = np.zeros(ext, np.float32)
+            out[sl] = x
+            return out
+        hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-4, 3)
+        orc.set_quotient_guard(True)
+        try:
+            return orc.cpu_deconvolve(embed(psi0), hp, 4)[sl]
+        finally:
+            orc.set_quotient_guard(False)
+
+    import ctypes
+
+    def has_plan(ext):  # the engine of a call takes its plan from the plan store
+        return emu.l.mvn_plan_store_has_key(0, (ctypes.c_int * 3)(*ext)) == 1
+
+    emu.l.mvn_release_cached_engines()
+    emu.check(emu.l.mvn_plan_store_clear())
+    got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert expected_good_extent(emu, 32, False) == 32 and expected_good_extent(emu, 32, True) == 32
+    assert has_plan((23, 32, 32)) and not has_plan((24, 32, 32))
+    exact, rounded = reference((23, 32, 32)), reference((24, 32, 32))
+    assert np.abs(got - exact).max() <= 1e-4 * np.abs(exact).max()
+    # (the extra plane holds zeros the guarded quotient never lets in: the two paddings agree to rounding)
+    assert np.abs(exact - rounded).max() <= 1e-5 * np.abs(exact).max()
+    monkeypatch.setenv("MVN_DIM0_DIRECT", "0")
+    emu.l.mvn_release_cached_engines()
+    emu.check(emu.l.mvn_plan_store_clear())
+    got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert has_plan((24, 32, 32)) and not has_plan((23, 32, 32))
+    assert np.abs(got - rounded).max() <= 1e-4 * np.abs(rounded).max()
     emu.l.mvn_release_cached_engines()

@@ -1271,6 +1271,49 @@ def test_direct_dim0_leg_in_a_child_process(gpu, direct):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # "1": the default (separate Nyquist plane under the direct leg); "1 packed": MVN_NYQ_PACKED=1, the Nyquist
     # bins packed into the DC column and separated inside the direct leg (no Nyquist launches, one stream)
-    env = dict(os.environ, MVN_DIM0_DIRECT=direct[0], MVN_DIM0_DIRECT_MAX="33", MVN_NYQ_PACKED="1" if "packed" in direct else "0")
+    env = dict(os.environ, MVN_DIM0_DIRECT=direct[0], MVN_DIM0_DIRECT_MAX="33", MVN_DIM0_DIRECT_MIN_PLANE="0",
+               MVN_NYQ_PACKED="1" if "packed" in direct else "0")
     r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD, root], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "direct child ok " + direct[0] in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_default_policy_keeps_dim0_exact_under_the_direct_leg(gpu, orc, monkeypatch):
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")  # read per call / per engine
+    # zero_padd with FFT-friendly extents pads dim1 / dim2 to good sizes but leaves dim0 at the reference's exact
+    # image + kernel - 1 when every PSF is thin enough for the direct dim0 leg (no transform along dim0) and d1
+    # keeps whole last-axis tiles: 20 + 4 - 1 = 23 planes (not 24), 26 + 7 - 1 = 32, 30 + 3 - 1 = 32.  With the
+    # direct leg switched off the old rule applies (24 planes).
+    from ref_fixtures import expected_good_extent
+    shape = (20, 26, 30)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (4, 7, 3), seed=12)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    off = (1, 3, 1)  # (kernel - 1) / 2
+    sl = tuple(slice(o, o + s) for o, s in zip(off, shape))
+
+    def reference(ext):
+        def embed(x):
+            out = np.zeros(ext, np.float32)
+            out[sl] = x
+            return out
+        hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-4, 3)
+        orc.set_quotient_guard(True)
+        try:
+            return orc.cpu_deconvolve(embed(psi0), hp, 4)[sl]
+        finally:
+            orc.set_quotient_guard(False)
+
+    import ctypes
+
+    def has_plan(ext):  # the engine of a call takes its plan from the plan store
+        return gpu.l.mvn_plan_store_has_key(0, (ctypes.c_int * 3)(*ext)) == 1
+
+    gpu.l.mvn_release_cached_engines()
+    gpu.check(gpu.l.mvn_plan_store_clear())
+    got = gpu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert expected_good_extent(gpu, 32, False) == 32 and expected_good_extent(gpu, 32, True) == 32
+    assert has_plan((23, 32, 32)) and not has_plan((24, 32, 32))
+    exact, rounded = reference((23, 32, 32)), reference((24, 32, 32))
+    assert np.abs(got - exact).max() <= 1e-4 * np.abs(exact).max()
+    # (the extra plane holds zeros the guarded quotient never lets in: the two paddings agree to rounding)
+    assert np.abs(exact - rounded).max() <= 1e-5 * np.abs(exact).max()
+    gpu.check(gpu.l.mvn_release_cached_engines())

@@ -24,7 +24,9 @@ for i in range(n):
         if np.prod(shape) <= int(os.environ.get("FUZZ_MAX_VOXELS", "3000000")):
             break
     V = int(rng.integers(1, 4))
-    ks = tuple(int(min(s, rng.choice([1, 2, 3, 4, 5, 7]))) for s in shape)
+    # FUZZ_DEEP=1: PSF depths up to 35 along dim0 (the direct dim0 leg takes <= 33, deeper ones the fused FFT pass)
+    k0s = [1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 21, 30, 31, 33, 35] if os.environ.get("FUZZ_DEEP") else [1, 2, 3, 4, 5, 7]
+    ks = tuple(int(min(s, rng.choice(k0s if d == 0 else [1, 2, 3, 4, 5, 7]))) for d, s in enumerate(shape))
     lam = float(rng.choice([0.0, 0.006, 0.1]))
     its = int(rng.integers(1, 5))
     _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks, seed=int(rng.integers(1 << 30)))

@@ -1317,3 +1317,52 @@ def test_default_policy_keeps_dim0_exact_under_the_direct_leg(gpu, orc, monkeypa
     # (the extra plane holds zeros the guarded quotient never lets in: the two paddings agree to rounding)
     assert np.abs(exact - rounded).max() <= 1e-5 * np.abs(exact).max()
     gpu.check(gpu.l.mvn_release_cached_engines())
+
+
+def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
+    # (64, 512, 512) x 2 views x 31-plane PSFs: big enough planes for the direct dim0 leg by default.  Two runs
+    # from the same psi are bit-identical (no atomics, no order dependence on the staggered walk), and the
+    # direct leg agrees with the fused FFT leg of the same library to rounding.
+    import subprocess
+    import sys
+    shape, V = (64, 512, 512), 2
+    from ref_fixtures import structured_views
+    views, k1, k2, w, psi0 = structured_views(shape, V, (31, 9, 9), seed=3)
+
+    def run():
+        e = gpu.engine(shape, V)
+        for v in range(V):
+            e.set_view(v, views[v], w[v], k1[v], k2[v])
+        e.set_psi(psi0)
+        e.profile(True)
+        e.iterate(4, 0.006, 1e-4)
+        e.sync()
+        kinds = {n for n, (t, c) in e.profile_read().items() if c}
+        e.profile(False)
+        out = e.get_psi()
+        e.close()
+        return out, kinds
+
+    a, kinds = run()
+    b, _ = run()
+    assert "axis0_direct" in kinds and "axis0_fused" not in kinds, kinds
+    assert np.array_equal(a, b)
+    code = ("import os, sys, numpy as np\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+            "from libmultiviewnative_amd import native\n"
+            "from ref_fixtures import structured_views\n"
+            "g = native.lib(); shape, V = (64, 512, 512), 2\n"
+            "views, k1, k2, w, psi0 = structured_views(shape, V, (31, 9, 9), seed=3)\n"
+            "e = g.engine(shape, V)\n"
+            "[e.set_view(v, views[v], w[v], k1[v], k2[v]) for v in range(V)]\n"
+            "e.set_psi(psi0); e.iterate(4, 0.006, 1e-4); np.save(sys.argv[1], e.get_psi()); e.close()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "fft.npy")
+        r = subprocess.run([sys.executable, "-c", code % (root, root), out], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MVN_DIM0_DIRECT="0"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        fft = np.load(out)
+    mx, rms = rel_err(a, fft)
+    assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)

@@ -36,6 +36,9 @@ struct Dim0DirectParams {
   int h;               // k / 2
   long plane;          // bins per plane
   int stagger;         // workgroup w starts its (cyclic) walk at plane (w * stagger) mod d0: 0 = all at plane 0
+  int seg1;            // 0: a work item walks its whole column; > 0: the columns of the main array are cut into
+                       // pieces of seg1 output planes, one work item each (planes with few bins: 256^3 has 33 k
+                       // columns for 1024 wave slots), at the price of K + 3 window planes read again per piece
   // The Nyquist planes of the split layout ride in the same launch: bins [plane, plane + plane2) are the
   // bins of a second set of arrays with plane2 bins per plane (plane2 = 0: none).  A separate two-workgroup
   // launch on the side stream ran as long as the whole main launch (every work item walks all of dim0) and
@@ -60,6 +63,13 @@ struct Dim0DirectParams {
 
 #define MVN_D0_PF 4         // planes requested ahead
 #define MVN_D0_MAX_TAPS 33  // largest instantiated K
+
+// K the direct kernel is instantiated for: k itself if odd, else k + 1 (one zero tap)
+inline int mvn_dim0_taps_template(int k) { return k | 1; }
+inline bool mvn_dim0_direct_possible(int k, int d0) {
+  const int K = mvn_dim0_taps_template(k);
+  return k >= 1 && K <= MVN_D0_MAX_TAPS && d0 >= K + MVN_D0_PF;
+}
 
 // acc + a * w (complex): two packed fused multiply-adds on the device
 MVN_HD cfloat mvn_cmac(cfloat acc, cfloat a, cfloat w) {
@@ -124,15 +134,18 @@ MVN_HD void mvn_dim0_dc_compute(const Dim0DirectParams& P, int pair, const cfloa
 MVN_HD bool mvn_dim0_select(const Dim0DirectParams& P, long g, int wg_start, Dim0DirectParams& Q, long& b, int& z0,
                             int& nout) {
   Q = P;
-  if (g < P.plane) {
-    if (P.packed && g % P.C == 0) return false;  // the packed DC column belongs to the pair workgroups
-    b = g;
-    z0 = wg_start;
-    nout = P.d0;
+  const int seg1 = P.seg1 > 0 ? P.seg1 : P.d0;
+  const long main_items = P.plane * ((P.d0 + seg1 - 1) / seg1);
+  if (g < main_items) {
+    const long piece = g / P.plane;
+    b = g - piece * P.plane;
+    if (P.packed && b % P.C == 0) return false;  // the packed DC column belongs to the pair workgroups
+    z0 = P.seg1 > 0 ? (int)(piece * seg1) : wg_start;
+    nout = P.seg1 > 0 ? (P.d0 - z0 < seg1 ? P.d0 - z0 : seg1) : P.d0;
     return true;
   }
   if (P.plane2 <= 0 || P.packed) return false;
-  const long g2 = g - P.plane;
+  const long g2 = g - main_items;
   const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
   const long piece = g2 / P.plane2;
   b = g2 - piece * P.plane2;
@@ -147,9 +160,21 @@ MVN_HD bool mvn_dim0_select(const Dim0DirectParams& P, long g, int wg_start, Dim
 }
 // work items of a launch
 inline long mvn_dim0_items(const Dim0DirectParams& P) {
-  if (P.packed) return P.plane;  // + mvn_dim0_pairs(P.d1) workgroups, see the launchers
+  const int seg1 = P.seg1 > 0 ? P.seg1 : P.d0;
+  const long main_items = P.plane * ((P.d0 + seg1 - 1) / seg1);
+  if (P.packed) return main_items;  // + mvn_dim0_pairs(P.d1) workgroups, see the launchers
   const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
-  return P.plane + (P.plane2 > 0 ? P.plane2 * ((P.d0 + seg - 1) / seg) : 0);
+  return main_items + (P.plane2 > 0 ? P.plane2 * ((P.d0 + seg - 1) / seg) : 0);
+}
+// pieces the main columns of a (d0, plane) volume are cut into so that a launch has >= `want` work items, none
+// shorter than 2 K + 8 planes (0 = whole columns); -1 when even that does not give `want` items
+inline int mvn_dim0_piece_len(int k, int d0, long plane, long want) {
+  if (plane >= want) return 0;
+  const int K = mvn_dim0_taps_template(k);
+  const int min_len = 2 * K + 8;
+  const long need = (want + plane - 1) / plane;  // pieces
+  const int len = (int)((d0 + need - 1) / need);
+  return len >= min_len ? len : -1;
 }
 
 template <int K, int PF>
@@ -222,13 +247,6 @@ MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P, long b, int z0, in
       z = z + 1 == P.d0 ? 0 : z + 1;
     }
   }
-}
-
-// K the direct kernel is instantiated for: k itself if odd, else k + 1 (one zero tap)
-inline int mvn_dim0_taps_template(int k) { return k | 1; }
-inline bool mvn_dim0_direct_possible(int k, int d0) {
-  const int K = mvn_dim0_taps_template(k);
-  return k >= 1 && K <= MVN_D0_MAX_TAPS && d0 >= K + MVN_D0_PF;
 }
 
 // the instantiated tap counts, for the launch switches of both backends

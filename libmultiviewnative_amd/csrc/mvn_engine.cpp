@@ -767,7 +767,7 @@ void Engine::make_spectrum(const float* d_kernel, const int* kdims, float scale,
 // exactly as the volume's plan does (same kernel family => same position order of the spectra).
 bool Engine::direct_form(const int* kdims) {
   if (!direct_enabled_ || kdims[0] > direct_max_taps_ || !mvn_dim0_direct_possible(kdims[0], plan_->L.d0) ||
-      (long)plan_->L.d1 * plan_->L.C < direct_min_plane_)
+      mvn_dim0_piece_len(kdims[0], plan_->L.d0, (long)plan_->L.d1 * plan_->L.C, direct_min_plane_) < 0)
     return false;
   const int kd = ((kdims[0] + 1 + 15) / 16) * 16;
   const Plan3D* tp = taps_plan(kd);
@@ -859,6 +859,8 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   p.h = s.tap_k[i] / 2;
   p.plane = (long)L.d1 * L.C;
   p.stagger = d0_stagger_;
+  p.seg1 = mvn_dim0_piece_len(p.k, L.d0, p.plane, direct_min_plane_);
+  if (p.seg1 < 0) p.seg1 = 0;  // (forced on by the switches: whole columns)
   p.C = L.C;
   p.d1 = L.d1;
   if (packed_) {
@@ -907,7 +909,8 @@ bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
 bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
   const long plane = (long)d1 * (d2 % 2 == 0 ? d2 / 2 : (d2 + 1) / 2);
   return env_int("MVN_DIM0_DIRECT", 1) != 0 && k0 >= 1 && k0 <= env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS) &&
-         mvn_dim0_direct_possible(k0, d0) && plane >= (long)env_int("MVN_DIM0_DIRECT_MIN_PLANE", 98304);
+         mvn_dim0_direct_possible(k0, d0) &&
+         mvn_dim0_piece_len(k0, d0, plane, (long)env_int("MVN_DIM0_DIRECT_MIN_PLANE", 98304)) >= 0;
 }
 
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {
@@ -928,7 +931,11 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
                     stream_, prof, side, spec_tiled_);
     return;
   }
-  const bool use_side = side && side->s && P.L.even;
+  // The folded dim0 leg needs two fork / join pairs per convolution (17 - 20 us of cross-queue latency each):
+  // below MVN_D0_SIDE_MIN_MB (default 256) the Nyquist plane's two dim1 launches cost less in line
+  // (256^3 per view update: 0.329 ms with the side stream, 0.312 with the fused FFT pass)
+  static const size_t d0_side_min = (size_t)env_int("MVN_D0_SIDE_MIN_MB", 256) << 20;
+  const bool use_side = side && side->s && P.L.even && P.main_bytes() > d0_side_min;
   be::stream_t sn = use_side ? side->s : stream_;
   // MVN_D0_NYQ_SIDE=1: the Nyquist plane's whole chain (dim1, dim0 leg, dim1) on the side stream, one fork
   // and one join per convolution; default: its dim0 leg rides in the main launch, the side stream joins

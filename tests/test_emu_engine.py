@@ -782,9 +782,14 @@ def test_direct_dim0_leg_vs_fft_leg_and_oracle(emu, monkeypatch, k0):
     # "direct" / "staggered": Nyquist bins packed into the DC column (opt-in, every kernel is in the direct form);
     # "split": the separate Nyquist plane under the direct leg (the default)
     for tag, env in (("fft", {"MVN_DIM0_DIRECT": "0", "MVN_NYQ_PACKED": "1"}),
-                     ("direct", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "0", "MVN_NYQ_PACKED": "1"}),
+                     ("direct", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "0", "MVN_NYQ_PACKED": "1",
+                                 "MVN_DIM0_DIRECT_MIN_PLANE": "0"}),
                      ("staggered", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "7", "MVN_NYQ_PACKED": "1"}),
-                     ("split", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "7", "MVN_NYQ_PACKED": "0"})):
+                     ("split", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "7", "MVN_NYQ_PACKED": "0"}),
+                     # columns cut into pieces (planes with few bins; falls back to the FFT leg where a piece
+                     # would be shorter than 2 K + 8 planes)
+                     ("pieces", {"MVN_DIM0_DIRECT": "1", "MVN_NYQ_PACKED": "0", "MVN_DIM0_DIRECT_MIN_PLANE": "250"}),
+                     ("pieces packed", {"MVN_DIM0_DIRECT": "1", "MVN_NYQ_PACKED": "1", "MVN_DIM0_DIRECT_MIN_PLANE": "250"})):
         for kk, vv in env.items():
             monkeypatch.setenv(kk, vv)
         emu.l.mvn_release_cached_engines()
@@ -803,11 +808,11 @@ def test_direct_dim0_leg_vs_fft_leg_and_oracle(emu, monkeypatch, k0):
     emu.l.mvn_release_cached_engines()
     for lam in (0.0, 0.006):
         ref = orc.cpu_deconvolve(psi0, WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3), 4)
-        for tag in ("fft", "direct", "staggered", "split"):
+        for tag in ("fft", "direct", "staggered", "split", "pieces", "pieces packed"):
             assert np.abs(results[(tag, lam)] - ref).max() <= 1e-4 * np.abs(ref).max(), (tag, lam)
         assert np.array_equal(results[("direct", lam)], results[("staggered", lam)])  # same sums, another start plane
     ref = orc.cpu_deconvolve_simultaneous(psi0, WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2), 4)
-    for tag in ("fft", "direct", "staggered", "split"):
+    for tag in ("fft", "direct", "staggered", "split", "pieces", "pieces packed"):
         assert np.abs(results[(tag, "sim")] - ref).max() <= 1e-4 * np.abs(ref).max(), tag
 
 

@@ -615,11 +615,17 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
   direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 98304);  // columns per plane, see direct_ok_for()
   d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
-  // Opt-in: measured at 512^3 x 6 views x 31^3 PSFs the packed layout saves the Nyquist plane's 24 launches and
-  // every cross-queue wait of an iteration and is nevertheless 2 - 4 % SLOWER (13.1 - 13.4 against 12.85 ms:
-  // with the gaps gone the clock-sensitive passes - fused update +6 %, fused divide +3 %, the direct leg +6 % -
-  // lose more than the launches cost; profiles/r03_ab_packed_nyquist.txt)
-  packed_allowed_ = env_int("MVN_NYQ_PACKED", 0) != 0;
+  // Packed Nyquist layout (mvn_dim0_direct.hpp): MVN_NYQ_PACKED = 1 always / 0 never / unset: for volumes up to
+  // MVN_NYQ_PACKED_MAX_MB (default 256).  Small volumes are bound by launches and the Nyquist plane's 4 launches
+  // per view update are a fifth of their time (one view update: 256^3 0.291 -> 0.244 ms, 288^3 0.474 -> 0.421,
+  // 384^3 1.009 -> 0.968); at 512^3 the loop runs at the package power cap and the layout is 2 - 4 % SLOWER
+  // (13.1 - 13.4 against 12.85 ms per 6-view iteration: with the gaps gone the clock-sensitive passes lose more
+  // than the launches cost; profiles/r03_ab_packed_nyquist.txt, r03_power.md)
+  {
+    const int sw = env_int("MVN_NYQ_PACKED", -1);
+    const size_t max_bytes = (size_t)env_int("MVN_NYQ_PACKED_MAX_MB", 256) << 20;
+    packed_allowed_ = sw > 0 || (sw < 0 && plan_->main_bytes() <= max_bytes);
+  }
   for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);
 }

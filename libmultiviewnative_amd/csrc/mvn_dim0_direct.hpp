@@ -166,15 +166,21 @@ inline long mvn_dim0_items(const Dim0DirectParams& P) {
   const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
   return main_items + (P.plane2 > 0 ? P.plane2 * ((P.d0 + seg - 1) / seg) : 0);
 }
-// pieces the main columns of a (d0, plane) volume are cut into so that a launch has >= `want` work items, none
-// shorter than 2 K + 8 planes (0 = whole columns); -1 when even that does not give `want` items
+// Piece length for the main columns of a (d0, plane) volume: as many pieces as bring a launch to `want` work
+// items, but none shorter than 2 K + 8 planes (every piece reads its K + 3 window planes again); 0 = whole
+// columns.  mvn_dim0_items_for() = the work items that gives.
 inline int mvn_dim0_piece_len(int k, int d0, long plane, long want) {
-  if (plane >= want) return 0;
-  const int K = mvn_dim0_taps_template(k);
-  const int min_len = 2 * K + 8;
-  const long need = (want + plane - 1) / plane;  // pieces
-  const int len = (int)((d0 + need - 1) / need);
-  return len >= min_len ? len : -1;
+  if (plane >= want || plane < 1) return 0;
+  const int min_len = 2 * mvn_dim0_taps_template(k) + 8;
+  const long need = (want + plane - 1) / plane;
+  const long maxp = d0 / min_len;
+  const long pieces = need < maxp ? need : maxp;
+  if (pieces < 2) return 0;
+  return (int)((d0 + pieces - 1) / pieces);
+}
+inline long mvn_dim0_items_for(int k, int d0, long plane, long want) {
+  const int len = mvn_dim0_piece_len(k, d0, plane, want);
+  return len > 0 ? plane * ((d0 + len - 1) / len) : plane;
 }
 
 template <int K, int PF>

@@ -613,7 +613,8 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   // the whole iteration is 6.7 / 4.1 % faster than with the fused FFT pass at 15 / 31 planes
   direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
   direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
-  direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 98304);  // columns per plane, see direct_ok_for()
+  direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 65536);  // see direct_ok_for()
+  direct_min_items_ = env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
   d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
   // Packed Nyquist layout (mvn_dim0_direct.hpp): MVN_NYQ_PACKED = 1 always / 0 never / unset: for volumes up to
   // MVN_NYQ_PACKED_MAX_MB (default 256).  Small volumes are bound by launches and the Nyquist plane's 4 launches
@@ -773,7 +774,7 @@ void Engine::make_spectrum(const float* d_kernel, const int* kdims, float scale,
 // exactly as the volume's plan does (same kernel family => same position order of the spectra).
 bool Engine::direct_form(const int* kdims) {
   if (!direct_enabled_ || kdims[0] > direct_max_taps_ || !mvn_dim0_direct_possible(kdims[0], plan_->L.d0) ||
-      mvn_dim0_piece_len(kdims[0], plan_->L.d0, (long)plan_->L.d1 * plan_->L.C, direct_min_plane_) < 0)
+      mvn_dim0_items_for(kdims[0], plan_->L.d0, (long)plan_->L.d1 * plan_->L.C, direct_min_plane_) < direct_min_items_)
     return false;
   const int kd = ((kdims[0] + 1 + 15) / 16) * 16;
   const Plan3D* tp = taps_plan(kd);
@@ -866,7 +867,6 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   p.plane = (long)L.d1 * L.C;
   p.stagger = d0_stagger_;
   p.seg1 = mvn_dim0_piece_len(p.k, L.d0, p.plane, direct_min_plane_);
-  if (p.seg1 < 0) p.seg1 = 0;  // (forced on by the switches: whole columns)
   p.C = L.C;
   p.d1 = L.d1;
   if (packed_) {
@@ -907,16 +907,18 @@ void Engine::decide_layout() {
 
 bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
 
-// Is the direct dim0 leg the better one for PSFs of k0 planes on a (d0, d1, d2) volume?  Switches MVN_DIM0_DIRECT,
-// MVN_DIM0_DIRECT_MAX (deepest PSF, <= 33) and MVN_DIM0_DIRECT_MIN_PLANE: a work item walks a whole column, so
-// the leg needs enough columns (d1 * C bins per plane) to fill the chip - measured per view update with 15^3
-// PSFs (profiles/r03_shapes.txt): 256^3 (33 k columns) 0.371 against 0.302 ms with the fused FFT pass, 384^3
-// (74 k) 1.070 against 1.052, 512^3 (131 k) 2.14 against 2.32, 1024^3 17.4 against 19.9.
+// Is the direct dim0 leg to be used for PSFs of k0 planes on a (d0, d1, d2) volume?  Switches: MVN_DIM0_DIRECT,
+// MVN_DIM0_DIRECT_MAX (deepest PSF, <= 33), MVN_DIM0_DIRECT_MIN_PLANE (work items a launch should have: columns
+// are cut into pieces below that, default 65536) and MVN_DIM0_DIRECT_MIN_ITEMS (fewest work items for which the
+// leg is used at all, default 0: it wins at every size measured, profiles/r03_shapes.txt - 32^3 0.098 -> 0.062 ms
+// per view update, 128^3 0.132 -> 0.079, 256^3 0.311 -> 0.245, 512^3 2.31 -> 2.16, 1024^3 19.9 -> 17.4 - on small
+// volumes because the packed Nyquist layout it allows removes 6 of 14 launches).
 bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
   const long plane = (long)d1 * (d2 % 2 == 0 ? d2 / 2 : (d2 + 1) / 2);
   return env_int("MVN_DIM0_DIRECT", 1) != 0 && k0 >= 1 && k0 <= env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS) &&
          mvn_dim0_direct_possible(k0, d0) &&
-         mvn_dim0_piece_len(k0, d0, plane, (long)env_int("MVN_DIM0_DIRECT_MIN_PLANE", 98304)) >= 0;
+         mvn_dim0_items_for(k0, d0, plane, (long)env_int("MVN_DIM0_DIRECT_MIN_PLANE", 65536)) >=
+             (long)env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
 }
 
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {

@@ -777,13 +777,14 @@ def test_direct_dim0_leg_vs_fft_leg_and_oracle(emu, monkeypatch, k0):
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (k0, 5, 3), seed=50 + k0)
     k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]  # an asymmetric second kernel of the same depth
     monkeypatch.setenv("MVN_DIM0_DIRECT_MAX", "33")
-    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")  # (by default the leg is for planes of >= 98304 bins)
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_ITEMS", "0")  # (by default the leg is for planes of >= 98304 bins)
     results = {}
     # "direct" / "staggered": Nyquist bins packed into the DC column (opt-in, every kernel is in the direct form);
     # "split": the separate Nyquist plane under the direct leg (the default)
     for tag, env in (("fft", {"MVN_DIM0_DIRECT": "0", "MVN_NYQ_PACKED": "1"}),
                      ("direct", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "0", "MVN_NYQ_PACKED": "1",
-                                 "MVN_DIM0_DIRECT_MIN_PLANE": "0"}),
+                                 "MVN_DIM0_DIRECT_MIN_PLANE": "0", "MVN_DIM0_DIRECT_MIN_ITEMS": "0"}),
                      ("staggered", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "7", "MVN_NYQ_PACKED": "1"}),
                      ("split", {"MVN_DIM0_DIRECT": "1", "MVN_D0_STAGGER": "7", "MVN_NYQ_PACKED": "0"}),
                      # columns cut into pieces (planes with few bins; falls back to the FFT leg where a piece
@@ -821,6 +822,7 @@ def test_direct_dim0_leg_limits_and_nonfinite(emu, monkeypatch):
     # volume exactly as the FFT leg does (the update then clamps everything to minValue)
     monkeypatch.setenv("MVN_DIM0_DIRECT_MAX", "33")
     monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_ITEMS", "0")
     emu.l.mvn_release_cached_engines()
     for shape, kshape in (((40, 10, 12), (35, 3, 3)), ((12, 10, 12), (9, 3, 3)), ((8, 6, 10), (3, 3, 3))):
         _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=7)
@@ -842,6 +844,7 @@ def test_direct_dim0_leg_limits_and_nonfinite(emu, monkeypatch):
 
 def test_default_policy_keeps_dim0_exact_under_the_direct_leg(emu, monkeypatch):
     monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_ITEMS", "0")
     # zero_padd with FFT-friendly extents pads dim1 / dim2 to good sizes but leaves dim0 at the reference's exact
     # image + kernel - 1 when every PSF is thin enough for the direct dim0 leg (no transform along dim0) and d1
     # keeps whole last-axis tiles: 20 + 4 - 1 = 23 planes (not 24), 26 + 7 - 1 = 32, 30 + 3 - 1 = 32.  With the

@@ -1260,7 +1260,7 @@ print("direct child ok", os.environ.get("MVN_DIM0_DIRECT"), "%.2e" % worst)
 """
 
 
-@pytest.mark.parametrize("direct", ["1", "0", "1 packed"])
+@pytest.mark.parametrize("direct", ["1", "0", "1 packed", "1 product defaults"])
 def test_direct_dim0_leg_in_a_child_process(gpu, direct):
     # mvn_dim0_direct.hpp on the GPU: PSF depths 1 .. 33 (odd, even, the largest instantiated), d2 = 512
     # wave-row shapes and odd extents, sequential and simultaneous loops, against the oracle -- and the
@@ -1271,14 +1271,18 @@ def test_direct_dim0_leg_in_a_child_process(gpu, direct):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # "1": the default (separate Nyquist plane under the direct leg); "1 packed": MVN_NYQ_PACKED=1, the Nyquist
     # bins packed into the DC column and separated inside the direct leg (no Nyquist launches, one stream)
-    env = dict(os.environ, MVN_DIM0_DIRECT=direct[0], MVN_DIM0_DIRECT_MAX="33", MVN_DIM0_DIRECT_MIN_PLANE="0",
+    env = dict(os.environ, MVN_DIM0_DIRECT=direct[0], MVN_DIM0_DIRECT_MAX="33", MVN_DIM0_DIRECT_MIN_PLANE="0", MVN_DIM0_DIRECT_MIN_ITEMS="0",
                MVN_NYQ_PACKED="1" if "packed" in direct else "0")
+    if "defaults" in direct:  # what a host program gets: the leg at every size, columns in pieces, packed Nyquist
+        for k in ("MVN_DIM0_DIRECT_MIN_PLANE", "MVN_DIM0_DIRECT_MIN_ITEMS", "MVN_NYQ_PACKED", "MVN_DIM0_DIRECT_MAX"):
+            env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD, root], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "direct child ok " + direct[0] in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_default_policy_keeps_dim0_exact_under_the_direct_leg(gpu, orc, monkeypatch):
-    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")  # read per call / per engine
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_PLANE", "0")
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_ITEMS", "0")  # read per call / per engine
     # zero_padd with FFT-friendly extents pads dim1 / dim2 to good sizes but leaves dim0 at the reference's exact
     # image + kernel - 1 when every PSF is thin enough for the direct dim0 leg (no transform along dim0) and d1
     # keeps whole last-axis tiles: 20 + 4 - 1 = 23 planes (not 24), 26 + 7 - 1 = 32, 30 + 3 - 1 = 32.  With the

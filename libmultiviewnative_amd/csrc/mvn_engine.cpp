@@ -613,7 +613,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   // the whole iteration is 6.7 / 4.1 % faster than with the fused FFT pass at 15 / 31 planes
   direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
   direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
-  direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 65536);  // see direct_ok_for()
+  direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 131072);  // see direct_ok_for()
   direct_min_items_ = env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
   d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
   // Packed Nyquist layout (mvn_dim0_direct.hpp): MVN_NYQ_PACKED = 1 always / 0 never / unset: for volumes up to
@@ -909,7 +909,7 @@ bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
 
 // Is the direct dim0 leg to be used for PSFs of k0 planes on a (d0, d1, d2) volume?  Switches: MVN_DIM0_DIRECT,
 // MVN_DIM0_DIRECT_MAX (deepest PSF, <= 33), MVN_DIM0_DIRECT_MIN_PLANE (work items a launch should have: columns
-// are cut into pieces below that, default 65536) and MVN_DIM0_DIRECT_MIN_ITEMS (fewest work items for which the
+// are cut into pieces below that, default 131072) and MVN_DIM0_DIRECT_MIN_ITEMS (fewest work items for which the
 // leg is used at all, default 0: it wins at every size measured, profiles/r03_shapes.txt - 32^3 0.098 -> 0.062 ms
 // per view update, 128^3 0.132 -> 0.079, 256^3 0.311 -> 0.245, 512^3 2.31 -> 2.16, 1024^3 19.9 -> 17.4 - on small
 // volumes because the packed Nyquist layout it allows removes 6 of 14 launches).
@@ -917,7 +917,7 @@ bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
   const long plane = (long)d1 * (d2 % 2 == 0 ? d2 / 2 : (d2 + 1) / 2);
   return env_int("MVN_DIM0_DIRECT", 1) != 0 && k0 >= 1 && k0 <= env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS) &&
          mvn_dim0_direct_possible(k0, d0) &&
-         mvn_dim0_items_for(k0, d0, plane, (long)env_int("MVN_DIM0_DIRECT_MIN_PLANE", 65536)) >=
+         mvn_dim0_items_for(k0, d0, plane, (long)env_int("MVN_DIM0_DIRECT_MIN_PLANE", 131072)) >=
              (long)env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
 }
 

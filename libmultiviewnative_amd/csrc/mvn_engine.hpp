@@ -338,7 +338,7 @@ class Engine {
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;
   int direct_max_taps_ = MVN_D0_MAX_TAPS;
-  long direct_min_plane_ = 65536, direct_min_items_ = 0;
+  long direct_min_plane_ = 131072, direct_min_items_ = 0;
   std::map<int, std::unique_ptr<Plan3D>> taps_plans_;  // (kd, d1, d2) plans of the tap arrays, private to the engine
   // second work volume: the direct dim0 leg is out of place, work_ and work2_ swap roles after it
   float* work2_ = nullptr;

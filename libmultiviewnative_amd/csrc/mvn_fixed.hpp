@@ -173,7 +173,26 @@ constexpr int fx_rowoff(int j) {
 // ---------------------------------------------------------------------------------------------
 // one radix stage, fully unrolled for NT threads
 // ---------------------------------------------------------------------------------------------
-template <int N, int T, int TP, bool PAD, int NT, int S, int SIGN, bool DIF>
+// twiddle row j2 of stage S out of a stage-ordered table: rows of fx_rs(R) entries, or (TWT: the LDS copies of
+// the walking last-axis kernels, fx_rows_tables) 16-byte pairs {k, k + 1} stored [k / 2][j2], so that lanes
+// with neighbouring j2 read neighbouring 16-byte slots.  Row-wise the lanes of a ds_read_b128 group sit 64
+// bytes apart on 4 slots: a 4-way bank conflict on every twiddle read of these kernels, whose lanes run along
+// j2 (52 - 61 % of the LDS cycles of the fused pass at H = 960 / 288 were conflict cycles and the LDS was busy
+// 81 % of the pass; profiles/r03_rows_lds.md).  The strided kernels' lanes run along the columns of one row
+// and read a twiddle row as a broadcast: they keep the row-wise table.
+template <int N, int S, bool TWT>
+MVN_HD void fx_tw_fetch(const cfloat* tws, int j2, cfloat* tw) {
+  constexpr int R = fx_radix(N, S), M = fx_M(N, S), Q = fx_rs(R) / 2;
+  const qfloat* t4 = reinterpret_cast<const qfloat*>(tws + fx_twoff(N, S));
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const qfloat t = TWT ? t4[k * M + j2] : t4[j2 * Q + k];
+    tw[2 * k] = cmake(t.x, t.y);
+    tw[2 * k + 1] = cmake(t.z, t.w);
+  }
+}
+
+template <int N, int T, int TP, bool PAD, int NT, int S, int SIGN, bool DIF, bool TWT = false>
 MVN_HD void fx_stage(cfloat* buf, const cfloat* tws, int tid) {
   constexpr int R = fx_radix(N, S), M = fx_M(N, S);
   constexpr int nwork = (N / R) * T;
@@ -182,22 +201,21 @@ MVN_HD void fx_stage(cfloat* buf, const cfloat* tws, int tid) {
   for (int it = 0; it < iters; ++it) {
     const int w = tid + it * NT;
     if (nwork % NT != 0 && w >= nwork) break;
-    const int b = w / T, c = w % T;
+    // Walking last-axis kernels with 2 or 4 tile rows (TWT, TP = 3 or 5): lanes run along the butterflies of
+    // one tile row - their words sit TP apart, every bank pair once per lane group - instead of along the tile
+    // rows of one butterfly (2-way conflicts between neighbouring butterflies).  8-row tiles keep the
+    // row-fastest order: 8 neighbouring words per butterfly are already conflict-free and share a twiddle row.
+    // (576^3: -2.3 % per view update, 1920-long rows: fused divide -3 %, 384^3 with 8 rows: +2 % and left alone;
+    // profiles/r03_rows_lds.md)
+    constexpr bool JF = TWT && T <= 4;
+    const int b = JF ? w % (N / R) : w / T, c = JF ? w / (N / R) : w % T;
     const int blk = b / M, j2 = b % M;
     cfloat* p = buf + fx_row<PAD>(blk * R * M + j2) * TP + c;
     cfloat a[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) a[j] = p[fx_rowoff<PAD, R, M>(j) * TP];
     cfloat tw[fx_rs(R)];
-    if (M > 1) {
-      const qfloat* t4 = reinterpret_cast<const qfloat*>(tws + fx_twoff(N, S) + j2 * fx_rs(R));
-#pragma unroll
-      for (int k = 0; k < fx_rs(R) / 2; ++k) {
-        const qfloat t = t4[k];
-        tw[2 * k] = cmake(t.x, t.y);
-        tw[2 * k + 1] = cmake(t.z, t.w);
-      }
-    }
+    if (M > 1) fx_tw_fetch<N, S, TWT>(tws, j2, tw);
     if (!DIF && M > 1) {
 #pragma unroll
       for (int k = 1; k < R; ++k) a[k] = cmul_dir<SIGN>(a[k], tw[k]);
@@ -213,27 +231,27 @@ MVN_HD void fx_stage(cfloat* buf, const cfloat* tws, int tid) {
 }
 
 // stages LO..ns-1 of a transform as phases (DIF runs them upwards from LO, DIT downwards to LO)
-template <int N, int T, int TP, bool PAD, int NT, int SIGN, bool DIF, int S, int LO, typename Ctx>
+template <int N, int T, int TP, bool PAD, int NT, int SIGN, bool DIF, int S, int LO, bool TWT, typename Ctx>
 struct FxStages {
   static MVN_HD void run(cfloat* buf, const cfloat* tws, Ctx& ctx) {
     constexpr int NT_ = NT;
     (void)NT_;
-    MVN_PHASE(ctx, (fx_stage<N, T, TP, PAD, NT, S, SIGN, DIF>(buf, tws, tid)));
+    MVN_PHASE(ctx, (fx_stage<N, T, TP, PAD, NT, S, SIGN, DIF, TWT>(buf, tws, tid)));
     constexpr int next = DIF ? S + 1 : S - 1;
     if constexpr (next >= LO && next < fx_nstages(N))
-      FxStages<N, T, TP, PAD, NT, SIGN, DIF, next, LO, Ctx>::run(buf, tws, ctx);
+      FxStages<N, T, TP, PAD, NT, SIGN, DIF, next, LO, TWT, Ctx>::run(buf, tws, ctx);
   }
 };
 
-template <int N, int T, int TP, bool PAD, int NT, int SIGN, int LO = 0, typename Ctx>
+template <int N, int T, int TP, bool PAD, int NT, int SIGN, int LO = 0, bool TWT = false, typename Ctx>
 MVN_HD void fx_dif(cfloat* buf, const cfloat* tws, Ctx& ctx) {
   if constexpr (LO < fx_nstages(N))
-    FxStages<N, T, TP, PAD, NT, SIGN, true, LO, LO, Ctx>::run(buf, tws, ctx);
+    FxStages<N, T, TP, PAD, NT, SIGN, true, LO, LO, TWT, Ctx>::run(buf, tws, ctx);
 }
-template <int N, int T, int TP, bool PAD, int NT, int SIGN, int LO = 0, typename Ctx>
+template <int N, int T, int TP, bool PAD, int NT, int SIGN, int LO = 0, bool TWT = false, typename Ctx>
 MVN_HD void fx_dit(cfloat* buf, const cfloat* tws, Ctx& ctx) {
   if constexpr (LO < fx_nstages(N))
-    FxStages<N, T, TP, PAD, NT, SIGN, false, fx_nstages(N) - 1, LO, Ctx>::run(buf, tws, ctx);
+    FxStages<N, T, TP, PAD, NT, SIGN, false, fx_nstages(N) - 1, LO, TWT, Ctx>::run(buf, tws, ctx);
 }
 
 template <int NT>
@@ -1063,6 +1081,8 @@ struct FxRowsCfg {
                                                                            : 0;
   static constexpr bool SMALL = WALK_T > 0;
   static constexpr bool WALK = SMALL;
+  // walking kernels transpose the stage twiddles when they copy them to the LDS (fx_tw_fetch)
+  static constexpr bool TWT = WALK;
   static constexpr int T = SMALL ? WALK_T : (H > 512 ? 8 : ((fx_pow2(H) && H >= 128) ? MVN_FX_ROWS_T : 16));
   static constexpr int TP = T + 1;
   static constexpr int QR = H / 2;  // 16-byte chunks per spectral row (2 complex bins each)
@@ -1135,7 +1155,21 @@ MVN_HD void fx_load_tw_row(const cfloat* row, cfloat* tw) {
 template <int H>
 MVN_HD void fx_rows_tables(const RowsParams& P, cfloat* tws, cfloat* twr, int tid) {
   typedef FxRowsCfg<H> C;
-  fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(H), tid);
+  if constexpr (C::TWT) {
+    // stage blocks transposed to [k / 2][j2] 16-byte pairs, see fx_tw_fetch
+    for (int st = 0; st < fx_nstages(H); ++st) {
+      const int M = fx_M(H, st), Q = fx_rs(fx_radix(H, st)) / 2;
+      if (M <= 1) continue;
+      const qfloat* src = reinterpret_cast<const qfloat*>(P.ax.tws + fx_twoff(H, st));
+      qfloat* dst = reinterpret_cast<qfloat*>(tws + fx_twoff(H, st));
+      for (int i = tid; i < M * Q; i += C::NT) {
+        const qfloat t = src[i];
+        dst[(i % Q) * M + i / Q] = qmake(t.x, t.y, t.z, t.w);
+      }
+    }
+  } else {
+    fx_copy_table<C::NT>(tws, P.ax.tws, fx_twsize(H), tid);
+  }
   fx_copy_table<C::NT>(twr, P.twr, H / 2 + 1, tid);
   fx_build_pair_table<H>(reinterpret_cast<FxPair*>(twr + C::TWR), tid);
 }
@@ -1164,7 +1198,10 @@ MVN_HD void fx_r2c_load_stage0(const RowsParams& P, long r0, cfloat* buf, cfloat
     const int j2 = w % M, rho = w / M;
     cfloat tw[fx_rs(R)];
     // stage 0 opens the table; a one-tile workgroup's LDS copy is not ready yet
-    fx_load_tw_row<R>((C::WALK ? (const cfloat*)tws : P.ax.tws) + j2 * fx_rs(R), tw);
+    if constexpr (C::WALK)
+      fx_tw_fetch<H, 0, C::TWT>(tws, j2, tw);
+    else
+      fx_load_tw_row<R>(P.ax.tws + j2 * fx_rs(R), tw);
     dftR<R, -1>(a[it]);
 #pragma unroll
     for (int k = 1; k < R; ++k) a[it][k] = cmul(a[it][k], tw[k]);
@@ -1235,7 +1272,7 @@ MVN_HD void fx_rows_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_r2c_load_stage0<H>(P, r0, buf, tws, twr, tid)));
-  fx_dif<H, T, TP, C::PAD, NT, -1, 1>(buf, tws, ctx);
+  fx_dif<H, T, TP, C::PAD, NT, -1, 1, C::TWT>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
 }
@@ -1345,7 +1382,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
 #pragma unroll
     for (int k = 0; k < R; ++k) a[k] = p[fx_rowoff<C::PAD, R, M>(k) * TP];
     cfloat tw[fx_rs(R)];
-    fx_load_tw_row<R>(tws + j2 * fx_rs(R), tw);
+    fx_tw_fetch<H, 0, C::TWT>(tws, j2, tw);
 #pragma unroll
     for (int k = 1; k < R; ++k) a[k] = cmulc(a[k], tw[k]);
     dftR<R, +1>(a);  // a[jo] = z[j2 + M*jo] = (x[2j], x[2j+1])
@@ -1384,9 +1421,9 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
 #ifndef MVN_EXP_SKIP_PREPOST  // timing experiment only (wrong results): what two LDS round trips cost
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
 #endif
-  fx_dit<H, T, TP, C::PAD, NT, +1, 1>(buf, tws, ctx);
+  fx_dit<H, T, TP, C::PAD, NT, +1, 1, C::TWT>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, true, EPI>(P, r0, buf, tws, r, tid)));
-  fx_dif<H, T, TP, C::PAD, NT, -1, 1>(buf, tws, ctx);
+  fx_dif<H, T, TP, C::PAD, NT, -1, 1, C::TWT>(buf, tws, ctx);
 #ifndef MVN_EXP_SKIP_PREPOST
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
 #endif
@@ -1404,7 +1441,7 @@ MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
-  fx_dit<H, T, TP, C::PAD, NT, +1, 1>(buf, tws, ctx);
+  fx_dit<H, T, TP, C::PAD, NT, +1, 1, C::TWT>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, false, EPI>(P, r0, buf, tws, r, tid)));
 }
 

@@ -76,6 +76,22 @@ def test_mixed_radix_fixed_deconvolve_vs_oracle(emu):
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+# every last-axis length of the walking (row-major tile) kernels through the fused c2r + pointwise + r2c passes
+WALKING_D2 = [96, 160, 288, 320, 384, 576, 640, 768, 960, 1280, 1536, 1920, 2048]
+
+
+@pytest.mark.parametrize("d2", WALKING_D2)
+def test_walking_rows_kernels_deconvolve_vs_oracle(emu, d2):
+    shape = (4, 16, d2)
+    assert emu.plan_describe(shape)["fx_rows"] == 1
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (3, 3, 5))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    got = emu.gpu_deconvolve(psi0, h)
+    ref = orc.cpu_deconvolve(psi0, h, 4)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-5 * np.sqrt(np.mean(ref ** 2))
+
+
 def test_fixed_kernels_deconvolve_vs_oracle(emu):
     shape = (64, 64, 128)
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 7, 9))

@@ -126,6 +126,19 @@ def test_mixed_radix_fixed_deconvolve_vs_oracle(gpu, orc):
         assert mx <= MAX_REL and rms <= RMS_REL
 
 
+# every last-axis length of the walking (row-major tile) kernels through the fused c2r + pointwise + r2c passes,
+# with tiles left over for the walk (rows = 96: more tiles than one sweep of some lengths, fewer of others)
+@pytest.mark.parametrize("d2", [96, 160, 288, 320, 384, 576, 640, 768, 960, 1280, 1536, 1920, 2048])
+def test_walking_rows_kernels_deconvolve_vs_oracle(gpu, orc, d2):
+    shape = (6, 16, d2)
+    assert gpu.plan_describe(shape)["fx_rows"] == 1
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (3, 3, 5))
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+        mx, rms = rel_err(gpu.gpu_deconvolve(psi0, h), orc.cpu_deconvolve(psi0, h, 8))
+        assert mx <= MAX_REL and rms <= RMS_REL
+
+
 BLUESTEIN_SHAPES = [(37, 41, 74), (4, 271, 6), (271, 4, 8), (6, 5, 542), (67, 8, 134), (3, 3, 37),
                     (127, 131, 262)]
 

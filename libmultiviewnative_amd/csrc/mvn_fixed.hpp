@@ -822,6 +822,9 @@ struct FxSplitCfg {
 template <int N>
 struct FxSplitRegs {
   qfloat a[8 * FxSplitCfg<N>::IT0];  // the whole tile: rows j2 + k M0 of IT0 work items
+  // the rows of a window between their global loads and the last stage; window 1's are requested while window 0
+  // is in its inner stages, where `a` is still empty
+  qfloat pf[FxSplitCfg<N>::ITL * FxSplitCfg<N>::RL];
 };
 
 // an inner stage on one window (rows are window-relative; sub-lines never straddle windows)
@@ -893,20 +896,25 @@ MVN_HD void fx_sp_collect(const cfloat* buf, FxSplitRegs<N>& r, int tid) {
   }
 }
 
-// entry of a window: loads with the last stage's mapping (positions win W + b RL + k), that
-// stage (M = 1, no twiddles) in registers.  PERM: position p is fetched from row rev(p) -- the
-// forward transform reads its natural-order input in digit-reversed order.
-template <int N, int SIGN, bool PERM>
-MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int win, int tid) {
+// entry of a window, in two halves.  fx_sp_fetch: the global loads with the last stage's mapping (positions
+// win W + b RL + k) into r.pf, items [IT_LO, IT_HI) of the thread.  PERM: position p is fetched from row
+// rev(p) -- the forward transform reads its natural-order input in digit-reversed order.  fx_sp_last_to_lds:
+// that stage (M = 1, no twiddles) on r.pf, results to the LDS window.
+// With one 140 KB workgroup per CU nothing else covers a window's load latency: the loads of window 1 are
+// issued when window 0 has reached the LDS and fly during its inner stages, while the tile registers are still
+// empty (1920-long lines: forward 0.434 - 0.456 -> 0.417 - 0.421 ms, inverse 0.406 - 0.418 -> 0.393 - 0.401 ms at
+// 64 x 1920 x 1920).  Requesting the next tile's window 0 between the stores of the finished tile as well brought
+// the 1920 kernels to 256 VGPRs + 88 - 132 bytes of scratch and lost 8 - 20 % (profiles/r03_rows_lds.md).
+template <int N, bool PERM, int IT_LO, int IT_HI>
+MVN_HD void fx_sp_fetch(const StridedParams& P, long base, int win, FxSplitRegs<N>& r, int tid) {
   typedef FxSplitCfg<N> C;
-  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
+  constexpr int CH = C::CH, RL = C::RL;
   const cfloat* src0 = (P.src ? P.src : P.data) + base;
   // the last digit has weight W_last in the natural index: the RL rows of an item are equally
   // spaced either way
   const long kstep = PERM ? (long)fx_W(N, C::NS - 1) * P.estride : P.estride;
-  qfloat a[ITL * RL];
 #pragma unroll
-  for (int it = 0; it < ITL; ++it) {
+  for (int it = IT_LO; it < IT_HI; ++it) {
     int w = tid + it * C::NT;
     if (C::NWL % C::NT != 0 && w >= C::NWL) w = tid % C::NWL;  // clamped to a valid item: loaded, never used
     const int b = w / CH, q = w % CH;
@@ -914,11 +922,17 @@ MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int 
     long off = (long)(PERM ? fx_rev<N>(pos) : pos) * P.estride + 2 * q;
 #pragma unroll
     for (int k = 0; k < RL; ++k) {
-      a[it * RL + k] = *reinterpret_cast<const qfloat*>(src0 + off);
+      r.pf[it * RL + k] = *reinterpret_cast<const qfloat*>(src0 + off);
       off += kstep;
       MVN_JIT_ADDRESS(off);
     }
   }
+}
+
+template <int N, int SIGN>
+MVN_HD void fx_sp_last_to_lds(cfloat* buf, FxSplitRegs<N>& r, int tid) {
+  typedef FxSplitCfg<N> C;
+  constexpr int CH = C::CH, RL = C::RL, ITL = C::ITL;
 #pragma unroll
   for (int it = 0; it < ITL; ++it) {
     const int w = tid + it * C::NT;
@@ -926,7 +940,7 @@ MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int 
     const int b = w / CH, q = w % CH;
     qfloat x[RL];
 #pragma unroll
-    for (int k = 0; k < RL; ++k) x[k] = a[it * RL + k];
+    for (int k = 0; k < RL; ++k) x[k] = r.pf[it * RL + k];
     fx_dft_q<RL, SIGN>(x);
     qfloat* d = reinterpret_cast<qfloat*>(buf) + (b * RL) * C::TPQ + q;
 #pragma unroll
@@ -937,14 +951,14 @@ MVN_HD void fx_sp_load_last(const StridedParams& P, long base, cfloat* buf, int 
 
 // exit: stage 0 (twiddles first) on the registers, stored to global memory.  PERM: natural index
 // n = j2 + k M0 goes to row inv(n) -- the forward transform leaves its spectrum in position order.
-template <int N, int SIGN, bool PERM>
-MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* twl,
-                               FxSplitRegs<N>& r, int tid) {
+template <int N, int SIGN, bool PERM, int IT>
+MVN_HD void fx_sp_stage0_store_item(const StridedParams& P, long base, const cfloat* twl, FxSplitRegs<N>& r,
+                                    int tid) {
   typedef FxSplitCfg<N> C;
   const long rstep = (long)C::M0 * P.estride;
   cfloat* dst0 = P.data + base;
-#pragma unroll
-  for (int it = 0; it < C::IT0; ++it) {
+  constexpr int it = IT;
+  {
     const int w = tid + it * C::NT;
     const int q = w % C::CH, j2 = w / C::CH;
     cfloat tw[8];
@@ -971,6 +985,29 @@ MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* 
   }
 }
 
+template <int N, int SIGN, bool PERM, int IT>
+struct FxSplitStoreSteps {
+  static MVN_HD void run(const StridedParams& P, long base, const cfloat* twl, FxSplitRegs<N>& r, int tid) {
+    if constexpr (IT < FxSplitCfg<N>::IT0) {
+      fx_sp_stage0_store_item<N, SIGN, PERM, IT>(P, base, twl, r, tid);
+      FxSplitStoreSteps<N, SIGN, PERM, IT + 1>::run(P, base, twl, r, tid);
+    }
+  }
+};
+
+template <int N, int SIGN, bool PERM>
+MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* twl, FxSplitRegs<N>& r,
+                               int tid) {
+  FxSplitStoreSteps<N, SIGN, PERM, 0>::run(P, base, twl, r, tid);
+}
+
+template <int N>
+MVN_HD long fx_sp_base(const StridedParams& P, long block) {
+  const unsigned o = (unsigned)block / (unsigned)P.tiles_per_outer;
+  const unsigned t = (unsigned)block - o * (unsigned)P.tiles_per_outer;
+  return (long)o * P.ostride + (long)t * FxSplitCfg<N>::T;
+}
+
 // tiles first, first + step, ... < total (MODE is FWD or INV).  Both directions are decimation in
 // time -- the tile ACCUMULATES in registers window by window, so the registers fill up only at
 // the end (a decimation-in-frequency forward form, with every row live from the start, spilled
@@ -991,13 +1028,12 @@ MVN_HD void fx_strided_split_body(const StridedParams& P, long first, long total
   MVN_PHASE(ctx, (fx_sp_tables<N>(P, twl, tid)));
   for (long block = first; block < total; block += step) {
     MVN_TILE_LOOP_TOP(ctx);
-    const unsigned o = (unsigned)block / (unsigned)P.tiles_per_outer;
-    const unsigned t = (unsigned)block - o * (unsigned)P.tiles_per_outer;
-    const long base = (long)o * P.ostride + (long)t * C::T;
-    MVN_PHASE(ctx, (fx_sp_load_last<N, SIGN, PERM>(P, base, buf, 0, tid)));
+    const long base = fx_sp_base<N>(P, block);
+    MVN_PHASE_NOSYNC(ctx, (fx_sp_fetch<N, PERM, 0, C::ITL>(P, base, 0, r, tid)));
+    MVN_PHASE(ctx, (fx_sp_last_to_lds<N, SIGN>(buf, r, tid), fx_sp_fetch<N, PERM, 0, C::ITL>(P, base, 1, r, tid)));
     FxStagesQWin<N, SIGN, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
     MVN_PHASE(ctx, (fx_sp_collect<N, 0>(buf, r, tid)));
-    MVN_PHASE(ctx, (fx_sp_load_last<N, SIGN, PERM>(P, base, buf, 1, tid)));
+    MVN_PHASE(ctx, (fx_sp_last_to_lds<N, SIGN>(buf, r, tid)));
     FxStagesQWin<N, SIGN, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
     MVN_PHASE(ctx, (fx_sp_collect<N, 1>(buf, r, tid)));
     MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0_store<N, SIGN, PERM>(P, base, twl, r, tid)));

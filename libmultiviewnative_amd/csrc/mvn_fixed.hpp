@@ -803,7 +803,9 @@ struct FxSplitCfg {
   static constexpr int RL = fx_radix(N, NS - 1);
   static constexpr int W = N / 2;  // rows per window = 4 sub-lines
   static constexpr int NT1 = M0 * CH;
-  static constexpr int IT0 = fx_st_it0(NT1, 512);
+  // threads: 1280 runs best with 640 (two stage-0 items per thread; 320: +7 %), 1920 with 384 (five items; 640
+  // and 960 threads: +2 - 6 %) - profiles/r03_rows_lds.md
+  static constexpr int IT0 = fx_st_it0(NT1, N <= 1280 ? 640 : 512);
   static constexpr int NT = NT1 / IT0;
   static constexpr int NWL = (W / RL) * CH;  // last-stage work items per window
   static constexpr int ITL = (NWL + NT - 1) / NT;

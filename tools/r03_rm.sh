@@ -5,10 +5,12 @@ O=gpurun_out/r03rm
 mkdir -p $O
 rm -f $O/shapes.txt
 L=$PWD/libmultiviewnative_amd/lib
-MVN_PRODUCT_SO=$L/libmvn_ab_split8.so timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "long_lines or mixed_radix or config4" > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
-tail -2 $O/tests.log
+for v in $(cd $L && ls libmvn_ab_*.so); do
+MVN_PRODUCT_SO=$L/$v timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "long_lines or mixed_radix or config4_long" > $O/tests_$v.log 2>&1 || { tail -30 $O/tests_$v.log; exit 1; }
+tail -1 $O/tests_$v.log
+done
 export AB_NO_FFT=1
-for s in "64 1920 1920" "32 1280 1280" "64 1920 1920"; do
+for s in "64 1920 1920" "32 1280 1280" "64 1920 1920" "32 1280 1280"; do
   for v in $(cd $L && ls libmultiviewnative.so libmvn_ab_*.so); do
     echo "== $s $v" >> $O/shapes.txt
     MVN_PRODUCT_SO=$L/$v AB_SHAPE="$s" python3 tools/sweep.py "" >> $O/shapes.txt 2>&1

@@ -953,14 +953,14 @@ MVN_HD void fx_sp_last_to_lds(cfloat* buf, FxSplitRegs<N>& r, int tid) {
 
 // exit: stage 0 (twiddles first) on the registers, stored to global memory.  PERM: natural index
 // n = j2 + k M0 goes to row inv(n) -- the forward transform leaves its spectrum in position order.
-template <int N, int SIGN, bool PERM, int IT>
-MVN_HD void fx_sp_stage0_store_item(const StridedParams& P, long base, const cfloat* twl, FxSplitRegs<N>& r,
-                                    int tid) {
+template <int N, int SIGN, bool PERM>
+MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* twl, FxSplitRegs<N>& r,
+                               int tid) {
   typedef FxSplitCfg<N> C;
   const long rstep = (long)C::M0 * P.estride;
   cfloat* dst0 = P.data + base;
-  constexpr int it = IT;
-  {
+#pragma unroll
+  for (int it = 0; it < C::IT0; ++it) {
     const int w = tid + it * C::NT;
     const int q = w % C::CH, j2 = w / C::CH;
     cfloat tw[8];
@@ -985,22 +985,6 @@ MVN_HD void fx_sp_stage0_store_item(const StridedParams& P, long base, const cfl
     }
     MVN_SCHED_FENCE();
   }
-}
-
-template <int N, int SIGN, bool PERM, int IT>
-struct FxSplitStoreSteps {
-  static MVN_HD void run(const StridedParams& P, long base, const cfloat* twl, FxSplitRegs<N>& r, int tid) {
-    if constexpr (IT < FxSplitCfg<N>::IT0) {
-      fx_sp_stage0_store_item<N, SIGN, PERM, IT>(P, base, twl, r, tid);
-      FxSplitStoreSteps<N, SIGN, PERM, IT + 1>::run(P, base, twl, r, tid);
-    }
-  }
-};
-
-template <int N, int SIGN, bool PERM>
-MVN_HD void fx_sp_stage0_store(const StridedParams& P, long base, const cfloat* twl, FxSplitRegs<N>& r,
-                               int tid) {
-  FxSplitStoreSteps<N, SIGN, PERM, 0>::run(P, base, twl, r, tid);
 }
 
 template <int N>

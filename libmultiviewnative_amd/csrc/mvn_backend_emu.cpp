@@ -412,6 +412,8 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t) {
   if (p.packed) {
     if (!p.inv1 || !p.taps2 || (long)p.C * p.d1 != p.plane)
       throw std::invalid_argument("mvn: packed direct dim0 convolution needs the dim1 tables and the Nyquist taps");
+    if (mvn_dim0_dc_lds_bytes(p.d0, p.k) > 64 * 1024)  // the device launch's limit
+      throw std::invalid_argument("mvn: dim0 too long for the packed DC column");
 #pragma omp parallel
     {
       std::vector<cfloat> lds(2 * (size_t)p.d0 + 2 * (size_t)p.k);

@@ -85,6 +85,10 @@ MVN_HD cfloat mvn_cmac(cfloat acc, cfloat a, cfloat w) {
 
 // pairs (k1, -k1) of the packed DC column
 inline int mvn_dim0_pairs(int d1) { return d1 / 2 + 1; }
+// LDS of a DC-pair workgroup (two columns of d0 values + two sets of k taps) and the longest dim0 it allows:
+// 64 KB of dynamic LDS, 4062 planes at 33 taps.  Longer volumes keep the separate Nyquist plane.
+inline size_t mvn_dim0_dc_lds_bytes(int d0, int k) { return sizeof(cfloat) * (2 * (size_t)d0 + 2 * (size_t)k); }
+inline bool mvn_dim0_packed_possible(int d0) { return mvn_dim0_dc_lds_bytes(d0, MVN_D0_MAX_TAPS) <= 64 * 1024; }
 
 // One pair per workgroup, two phases around a workgroup barrier.  lds: 2 * d0 + 2 * k cfloats.
 MVN_HD void mvn_dim0_dc_load(const Dim0DirectParams& P, int pair, cfloat* lds, int tid, int nthreads) {

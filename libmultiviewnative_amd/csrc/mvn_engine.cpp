@@ -625,7 +625,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   {
     const int sw = env_int("MVN_NYQ_PACKED", -1);
     const size_t max_bytes = (size_t)env_int("MVN_NYQ_PACKED_MAX_MB", 256) << 20;
-    packed_allowed_ = sw > 0 || (sw < 0 && plan_->main_bytes() <= max_bytes);
+    packed_allowed_ = (sw > 0 || (sw < 0 && plan_->main_bytes() <= max_bytes)) && mvn_dim0_packed_possible(dims[0]);
   }
   for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);

@@ -751,7 +751,7 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
     if (!p.inv1 || !p.taps2 || p.C < 1 || p.d1 < 1 || (long)p.C * p.d1 != p.plane)
       throw std::invalid_argument("mvn: packed direct dim0 convolution needs the dim1 tables and the Nyquist taps");
     nblocks += mvn_dim0_pairs(p.d1);
-    lds = sizeof(cfloat) * (2 * (size_t)p.d0 + 2 * (size_t)p.k);
+    lds = mvn_dim0_dc_lds_bytes(p.d0, p.k);
     if (lds > 64 * 1024) throw std::invalid_argument("mvn: dim0 too long for the packed DC column");
   }
   if (nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");

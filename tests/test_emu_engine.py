@@ -92,6 +92,25 @@ def test_walking_rows_kernels_deconvolve_vs_oracle(emu, d2):
     assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-5 * np.sqrt(np.mean(ref ** 2))
 
 
+def test_packed_nyquist_layout_is_not_used_beyond_its_dim0_limit(emu, monkeypatch):
+    # a DC-pair workgroup of the packed layout keeps two dim0 columns in 64 KB of LDS: volumes with more than
+    # ~4000 planes keep the separate Nyquist plane (the launch would be refused), forced or not
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_ITEMS", "0")
+    shape = (4096, 4, 8)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 1, (3, 3, 3))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    ref = orc.cpu_deconvolve(psi0, h, 4)
+    for forced in (None, "1"):
+        if forced:
+            monkeypatch.setenv("MVN_NYQ_PACKED", forced)
+        emu.set_pad_mode("none")
+        try:
+            got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+        finally:
+            emu.set_pad_mode(None)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 def test_fixed_kernels_deconvolve_vs_oracle(emu):
     shape = (64, 64, 128)
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 7, 9))

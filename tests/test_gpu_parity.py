@@ -1242,7 +1242,8 @@ gpu = native.lib()
 assert gpu.backend_name() == "hip-gfx950"
 worst = 0.0
 for shape, kshape in [((64, 64, 64), (1, 5, 5)), ((64, 64, 64), (4, 5, 3)), ((96, 32, 64), (15, 7, 5)),
-                      ((64, 48, 512), (21, 5, 9)), ((80, 24, 40), (33, 3, 3)), ((40, 13, 17), (9, 5, 3))]:
+                      ((64, 48, 512), (21, 5, 9)), ((80, 24, 40), (33, 3, 3)), ((40, 13, 17), (9, 5, 3)),
+                      ((4096, 4, 8), (3, 3, 3))]:  # (the last: beyond the packed layout's dim0 limit)
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=sum(kshape))
     k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]
     for lam in (0.0, 0.006):

@@ -125,6 +125,18 @@ MVN_API int mvn_engine_delta_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats
 /* make the engine write its delta into caller-owned DEVICE memory (same size as the engine's
  * own buffer) so a collective library can reduce it in place; NULL restores the internal one */
 MVN_API int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr);
+/* Halo mode: one volume cut into dim0 slabs over several ranks, swept in the REFERENCE's view order
+ * (src/multiviewnative.cpp:194-227) - the engine's volume is this rank's planes plus h = (deepest PSF) / 2 halo
+ * planes either side (image 1, weights 0, psi anything there).  `fn(user, spectrum, view, conv)` is called on the
+ * calling thread right before every convolution's dim0 leg, with the engine's stream drained: it must fill planes
+ * [0, h) and [d0 - h, d0) of `spectrum` ([d0][d1][d2/2] complex, DEVICE memory) with the lower neighbour's last
+ * and the upper neighbour's first h own planes; mvn_engine_copy_planes moves whole planes between `spectrum` and
+ * an exchange buffer (to_buffer != 0: spectrum -> buffer) and returns when the copy is done.  Every PSF must have
+ * at most 33 planes (direct dim0 leg); NULL switches the mode off.  libmultiviewnative_amd/sharded.py drives it. */
+MVN_API int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void* user, void* spectrum, int view, int conv),
+                                     void* user);
+MVN_API int mvn_engine_copy_planes(mvn_engine* e, void* spectrum, int plane0, int nplanes, void* buffer,
+                                   int to_buffer);
 MVN_API int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);
 MVN_API int mvn_engine_stream(mvn_engine* e, void** hip_stream);
 MVN_API int mvn_engine_sync(mvn_engine* e);

@@ -927,6 +927,10 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
     // no Nyquist plane, no second stream: three launches on stream_
     if (!s.tap_k[i]) throw std::logic_error("mvn: packed Nyquist layout with a kernel that is not in the direct form");
     P.axis1(MVN_ST_FWD, (cfloat*)work_, nullptr, stream_, prof, stream_);
+    if (halo_fn_) {  // the neighbours' planes arrive in the halo planes of the leg's input
+      be::stream_sync(stream_);
+      halo_fn_(halo_user_, work_, (int)(&s - views_.data()), i);
+    }
     ensure_work2();
     dim0_conv(s, i, (const cfloat*)work_, nullptr, (cfloat*)work2_, nullptr, prof, stream_);
     std::swap(work_, work2_);
@@ -934,6 +938,8 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
     P.axis1(MVN_ST_INV, (cfloat*)work_, nullptr, stream_, prof, stream_);
     return;
   }
+  if (halo_fn_)
+    throw std::logic_error("mvn: halo mode needs every PSF in the direct form (<= 33 planes) and the packed Nyquist layout");
   if (!s.tap_k[i]) {
     P.middle_passes((cfloat*)work_, work_nyq_, (const cfloat*)(i == 0 ? s.spec1 : s.spec2), i == 0 ? s.nyq1 : s.nyq2,
                     stream_, prof, side, spec_tiled_);
@@ -1174,7 +1180,7 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
   static const bool no_fuse = env_int("MVN_NO_FUSE", 0) != 0;
   // (a captured sweep holds buffer addresses: the two work volumes must be back in their roles after it,
   // i.e. the sweep must contain an even number of direct dim0 legs)
-  bool use_graph = graphs_on && iterations >= 3 && !prof_.enabled && plan_->can_fuse_rows() &&
+  bool use_graph = graphs_on && !halo_fn_ && iterations >= 3 && !prof_.enabled && plan_->can_fuse_rows() &&
                    !no_fuse && plan_->main_bytes() <= graph_max_bytes;
   for (int it = 0; it < iterations; ++it) {
     if (use_graph && it == 1) {  // every view has been staged by now: its PSF forms are known
@@ -1224,6 +1230,30 @@ float* Engine::delta_ptr() {
     be::dzero(delta_, plan_->main_bytes(), stream_);
   }
   return delta_;
+}
+
+void Engine::set_halo_hook(halo_fn_t fn, void* user) {
+  if (fn) {
+    if (!plan_->L.even || !mvn_dim0_packed_possible(plan_->L.d0))
+      throw std::invalid_argument("mvn: halo mode needs an even last extent and at most 4062 planes per rank");
+    packed_allowed_ = true;
+  }
+  halo_fn_ = fn;
+  halo_user_ = user;
+}
+
+void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer) {
+  be::set_device(device_);
+  const Layout& L = plan_->L;
+  if (!spectrum || !buffer || plane0 < 0 || nplanes < 1 || plane0 + nplanes > L.d0)
+    throw std::invalid_argument("mvn: copy_planes out of range");
+  const size_t pb = (size_t)L.d1 * (size_t)L.C * sizeof(cfloat);
+  char* p = (char*)spectrum + (size_t)plane0 * pb;
+  if (to_buffer)
+    be::d2d(buffer, p, (size_t)nplanes * pb, stream_);
+  else
+    be::d2d(p, buffer, (size_t)nplanes * pb, stream_);
+  be::stream_sync(stream_);
 }
 
 void Engine::bind_delta(float* external) {

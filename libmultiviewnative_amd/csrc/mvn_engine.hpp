@@ -272,6 +272,14 @@ class Engine {
   // use caller-owned device memory (volume_floats() floats) as the delta buffer, so that a
   // collective library can all-reduce it in place; nullptr returns to an engine-owned buffer
   void bind_delta(float* external);
+  // Halo mode (dim0 slabs of one volume on several ranks, reference update order): the engine's volume is this
+  // rank's planes with h halo planes either side; `fn` is called on the host right before every dim0 leg, with
+  // the stream drained, and fills the halo planes of `spectrum` (the leg's input, [d0][d1][C] complex, packed
+  // Nyquist layout) with the neighbours' planes (copy_planes moves planes between it and exchange buffers).
+  // Needs every PSF in the direct form and the packed layout; throws at the first sweep otherwise.
+  typedef void (*halo_fn_t)(void* user, void* spectrum, int view, int conv);
+  void set_halo_hook(halo_fn_t fn, void* user);
+  void copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer);
   float* psi_ptr() { return psi_; }
   size_t volume_floats() const { return plan_->L.real_floats(); }
   // Host stacks of extents `dims` live at offset `off` inside the engine's (larger) volume, the
@@ -335,6 +343,8 @@ class Engine {
   cfloat* wn() const { return packed_ ? nullptr : work_nyq_; }
   cfloat* pn() const { return packed_ ? nullptr : psi_spec_nyq_; }
   bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
+  halo_fn_t halo_fn_ = nullptr;
+  void* halo_user_ = nullptr;
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;
   int direct_max_taps_ = MVN_D0_MAX_TAPS;

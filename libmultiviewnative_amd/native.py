@@ -36,7 +36,7 @@ ENGINE_ABI_SYMBOLS = [
     "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
     "mvn_engine_delta_chunks", "mvn_engine_delta_chunk_range", "mvn_engine_compute_delta_head",
     "mvn_engine_compute_delta_chunk", "mvn_engine_apply_delta_chunk",
-    "mvn_engine_bind_delta", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
+    "mvn_engine_bind_delta", "mvn_engine_set_halo_hook", "mvn_engine_copy_planes", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
     "mvn_engine_profile", "mvn_engine_profile_read", "mvn_kernel_kind_count",
     "mvn_kernel_kind_name", "mvn_engine_B",
     "mvn_slab_create", "mvn_slab_destroy", "mvn_slab_set_view", "mvn_slab_set_psi", "mvn_slab_get_psi",
@@ -123,6 +123,8 @@ class Binding:
         l.mvn_engine_delta_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.mvn_engine_psi_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.mvn_engine_bind_delta.argtypes = [C.c_void_p, C.c_void_p]
+        l.mvn_engine_set_halo_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.mvn_engine_copy_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         l.mvn_engine_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         l.mvn_engine_sync.argtypes = [C.c_void_p]
         l.mvn_engine_time_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_float,
@@ -389,6 +391,21 @@ class EngineHandle:
 
     def bind_delta(self, dev_ptr):
         self.b.check(self.b.l.mvn_engine_bind_delta(self.h, C.c_void_p(dev_ptr)))
+
+    HALO_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+
+    def set_halo_hook(self, fn):
+        """fn(spectrum_ptr, view, conv) before every dim0 leg (mvn_engine_set_halo_hook); None switches it off."""
+        if fn is None:
+            self._halo_cb = None
+            self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, None, None))
+            return
+        self._halo_cb = self.HALO_FN(lambda user, spectrum, view, conv: fn(spectrum, view, conv))
+        self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, C.cast(self._halo_cb, C.c_void_p), None))
+
+    def copy_planes(self, spectrum, plane0, nplanes, buffer_ptr, to_buffer):
+        self.b.check(self.b.l.mvn_engine_copy_planes(self.h, C.c_void_p(spectrum), plane0, nplanes,
+                                                     C.c_void_p(buffer_ptr), 1 if to_buffer else 0))
 
     def psi_ptr(self):
         return self._ptr(self.b.l.mvn_engine_psi_ptr)

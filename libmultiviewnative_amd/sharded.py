@@ -160,3 +160,101 @@ class SlabDriver:
                 last = it == iterations - 1 and v == num_views - 1
                 self.view_update(v, lambda_, min_value, not last)
         self.engine.sync()
+
+
+class HaloSlabDriver:
+    """One volume cut into dim0 slabs over the ranks, swept in the REFERENCE's view order (Gauss-Seidel,
+    src/multiviewnative.cpp:194-227): exact parity with the single-GPU path on any rank count.
+
+    Possible because the dim0 leg of a convolution is a direct K-tap convolution along dim0 in the (dim1, dim2)
+    spectral domain (``mvn_dim0_direct.hpp``): the last-axis and dim1 passes are local to a plane, and the dim0
+    leg of this rank's planes needs only the h = K // 2 planes either side of them - a halo exchange with the
+    two neighbouring ranks (cyclically: the reference's convolution is cyclic) of 2 h planes per convolution
+    instead of an all-reduce of the volume (view sharding) or two transposes of it (``SlabDriver``).
+
+    The engine is an ordinary resident engine on the EXTENDED slab, ``nz + 2 h`` planes: halo planes carry
+    image 1 / weights 0 and whatever the passes leave in them; before every dim0 leg the engine calls back
+    (``mvn_engine_set_halo_hook``) and the planes of the neighbours overwrite the halo planes of the leg's input.
+    Every PSF must have at most 33 planes along dim0 and ``nz >= h``.  Built and parity-tested on gloo ranks
+    (CPU emulation) and on one GPU; un-measured on several GPUs (the exchange here is synchronous).
+    """
+
+    def __init__(self, binding, full_shape, num_views, max_psf_depth, dist=None, rank=0, world=1, device=0,
+                 torch_device=None):
+        import torch
+        self.torch = torch
+        self.dist = dist if world > 1 else None
+        self.rank, self.world = rank, world
+        d0, d1, d2 = (int(x) for x in full_shape)
+        if d0 % world:
+            raise ValueError("halo mode: dim0 must divide by the rank count")
+        self.nz = d0 // world
+        self.h = int(max_psf_depth) // 2
+        if self.h < 1:
+            self.h = 1
+        if self.nz < self.h:
+            raise ValueError("halo mode: fewer planes per rank than halo planes")
+        self.z0 = rank * self.nz
+        self.ext_shape = (self.nz + 2 * self.h, d1, d2)
+        self.eng = binding.engine(self.ext_shape, num_views, device=device)
+        plane_floats = d1 * (d2 // 2) * 2
+        dev = torch_device if torch_device is not None else torch.device("cpu")
+        mk = lambda: torch.zeros(self.h * plane_floats, dtype=torch.float32, device=dev)
+        self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = mk(), mk(), mk(), mk()
+        self.error = None
+        self.eng.set_halo_hook(self._exchange)
+
+    # --- data in / out: the caller hands over its own planes [z0, z0 + nz) ----------------------------------
+    def _extend(self, local, fill):
+        import numpy as np
+        out = np.full(self.ext_shape, np.float32(fill), np.float32)
+        out[self.h:self.h + self.nz] = local
+        return out
+
+    def set_view(self, v, image_local, weights_local, kernel1, kernel2):
+        if max(kernel1.shape[0], kernel2.shape[0]) // 2 > self.h:
+            raise ValueError("halo mode: PSF deeper than the halo this driver was created for")
+        self.eng.set_view(v, self._extend(image_local, 1.0), self._extend(weights_local, 0.0), kernel1, kernel2)
+
+    def set_psi(self, psi_local):
+        self.eng.set_psi(self._extend(psi_local, float(psi_local.flat[0])))
+
+    def get_psi(self):
+        return self.eng.get_psi()[self.h:self.h + self.nz].copy()
+
+    # --- the exchange, called by the engine before every dim0 leg ------------------------------------------------
+    def _exchange(self, spectrum, view, conv):
+        if self.error is not None:
+            return
+        try:
+            e, h, nz = self.eng, self.h, self.nz
+            e.copy_planes(spectrum, h, h, self.send_lo.data_ptr(), True)    # my first h planes -> lower neighbour
+            e.copy_planes(spectrum, nz, h, self.send_hi.data_ptr(), True)   # my last h planes  -> upper neighbour
+            if self.dist is None:  # one rank: its own neighbour both ways (cyclic)
+                self.recv_hi.copy_(self.send_lo)
+                self.recv_lo.copy_(self.send_hi)
+            else:
+                d = self.dist
+                lower, upper = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+                # (tags keep the two messages of a pair apart on gloo when lower == upper; the order of the
+                # receives matches the order of the peer's sends for backends that match in issue order)
+                ops = [d.P2POp(d.isend, self.send_lo, lower, tag=0), d.P2POp(d.isend, self.send_hi, upper, tag=1),
+                       d.P2POp(d.irecv, self.recv_hi, upper, tag=0), d.P2POp(d.irecv, self.recv_lo, lower, tag=1)]
+                for r in d.batch_isend_irecv(ops):
+                    r.wait()
+                if self.send_lo.is_cuda:
+                    self.torch.cuda.synchronize()
+            e.copy_planes(spectrum, 0, h, self.recv_lo.data_ptr(), False)
+            e.copy_planes(spectrum, nz + h, h, self.recv_hi.data_ptr(), False)
+        except Exception as ex:  # a Python exception cannot cross the C frames of the engine
+            self.error = ex
+
+    def run(self, iterations, lam, min_value):
+        self.eng.iterate(iterations, lam, min_value)
+        self.eng.sync()
+        if self.error is not None:
+            raise self.error
+
+    def close(self):
+        self.eng.set_halo_hook(None)
+        self.eng.close()

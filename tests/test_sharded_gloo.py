@@ -184,3 +184,53 @@ def test_two_rank_slab_sweep_matches_sequential(tmp_path, case):
     one = e.get_psi()
     e.close()
     assert np.abs(got - one).max() <= 1e-6 * np.abs(one).max()
+
+
+# ---- dim0 slabs with halo exchange (HaloSlabDriver): the reference's update order on several ranks ---------------
+HALO_CASES = {"two_ranks": ((24, 16, 32), 2, 2, (7, 3, 5)), "four_ranks_even_depth": ((32, 16, 32), 2, 4, (4, 5, 3)),
+              "three_ranks_deep_psf": ((48, 32, 16), 1, 3, (15, 3, 3))}
+HALO_ITS = 3
+
+
+def _halo_worker(rank, world, port, out_dir, case):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MVN_DIM0_DIRECT_MIN_ITEMS"] = "0"  # the direct dim0 leg at every size: what the mode is built on
+    from libmultiviewnative_amd import native
+    from libmultiviewnative_amd.sharded import HaloSlabDriver
+    from ref_fixtures import realistic_views
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shape, V, _, ks = HALO_CASES[case]
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks)
+    emu = native.Binding(native.EMU_SO)
+    drv = HaloSlabDriver(emu, shape, V, ks[0], dist=dist, rank=rank, world=world)
+    sl = slice(drv.z0, drv.z0 + drv.nz)
+    for v in range(V):
+        drv.set_view(v, views[v][sl], w[v][sl], k1[v], k2[v])
+    drv.set_psi(psi0[sl])
+    drv.run(HALO_ITS, 0.006, 1e-4)
+    np.save(os.path.join(out_dir, "halo_rank%d.npy" % rank), drv.get_psi())
+    drv.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", sorted(HALO_CASES))
+def test_halo_slab_sweep_matches_the_sequential_oracle(tmp_path, case):
+    from oracle import binding as orc
+    from ref_fixtures import realistic_views
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    shape, V, world, ks = HALO_CASES[case]
+    mp.spawn(_halo_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("halo_rank%d.npy" % r)) for r in range(world)], axis=0)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, HALO_ITS)
+    ref = orc.cpu_deconvolve(psi0, h, 2)  # the reference's own (sequential) order: no Jacobi deviation
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()

@@ -1242,17 +1242,24 @@ void Engine::set_halo_hook(halo_fn_t fn, void* user) {
   halo_user_ = user;
 }
 
-void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer) {
+void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer) {
   be::set_device(device_);
   const Layout& L = plan_->L;
   if (!spectrum || !buffer || plane0 < 0 || nplanes < 1 || plane0 + nplanes > L.d0)
     throw std::invalid_argument("mvn: copy_planes out of range");
   const size_t pb = (size_t)L.d1 * (size_t)L.C * sizeof(cfloat);
   char* p = (char*)spectrum + (size_t)plane0 * pb;
-  if (to_buffer)
-    be::d2d(buffer, p, (size_t)nplanes * pb, stream_);
-  else
-    be::d2d(p, buffer, (size_t)nplanes * pb, stream_);
+  const size_t n = (size_t)nplanes * pb;
+  if (host_buffer) {
+    if (to_buffer)
+      be::d2h(buffer, p, n, stream_);
+    else
+      be::h2d(p, buffer, n, stream_);
+  } else if (to_buffer) {
+    be::d2d(buffer, p, n, stream_);
+  } else {
+    be::d2d(p, buffer, n, stream_);
+  }
   be::stream_sync(stream_);
 }
 

@@ -201,6 +201,9 @@ class HaloSlabDriver:
         dev = torch_device if torch_device is not None else torch.device("cpu")
         mk = lambda: torch.zeros(self.h * plane_floats, dtype=torch.float32, device=dev)
         self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = mk(), mk(), mk(), mk()
+        # exchange buffers in host memory (gloo has no device send / recv) under an engine on the GPU: the plane
+        # copies are device <-> host then; on the host emulation "device" memory is host memory either way
+        self.host_staging = (not self.send_lo.is_cuda) and binding.backend_name().startswith("hip")
         self.error = None
         self.eng.set_halo_hook(self._exchange)
 
@@ -228,8 +231,9 @@ class HaloSlabDriver:
             return
         try:
             e, h, nz = self.eng, self.h, self.nz
-            e.copy_planes(spectrum, h, h, self.send_lo.data_ptr(), True)    # my first h planes -> lower neighbour
-            e.copy_planes(spectrum, nz, h, self.send_hi.data_ptr(), True)   # my last h planes  -> upper neighbour
+            hs = self.host_staging
+            e.copy_planes(spectrum, h, h, self.send_lo.data_ptr(), True, hs)    # my first h planes -> lower neighbour
+            e.copy_planes(spectrum, nz, h, self.send_hi.data_ptr(), True, hs)   # my last h planes  -> upper neighbour
             if self.dist is None:  # one rank: its own neighbour both ways (cyclic)
                 self.recv_hi.copy_(self.send_lo)
                 self.recv_lo.copy_(self.send_hi)
@@ -244,8 +248,8 @@ class HaloSlabDriver:
                     r.wait()
                 if self.send_lo.is_cuda:
                     self.torch.cuda.synchronize()
-            e.copy_planes(spectrum, 0, h, self.recv_lo.data_ptr(), False)
-            e.copy_planes(spectrum, nz + h, h, self.recv_hi.data_ptr(), False)
+            e.copy_planes(spectrum, 0, h, self.recv_lo.data_ptr(), False, hs)
+            e.copy_planes(spectrum, nz + h, h, self.recv_hi.data_ptr(), False, hs)
         except Exception as ex:  # a Python exception cannot cross the C frames of the engine
             self.error = ex
 

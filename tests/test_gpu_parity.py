@@ -1087,6 +1087,34 @@ def test_bench_multi_rank_launch_path_vs_oracle(gpu, orc, tmp_path, launch):
     assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_halo_slab_mode_vs_the_sequential_oracle(gpu, orc, tmp_path, ranks):
+    # tools/halo_bench.py: ONE volume on dim0 slabs (halo exchange before every dim0 leg) in the REFERENCE's update
+    # order - one rank (cyclic self-exchange, device buffers) and two gloo ranks sharing device 0 (host staging)
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "psi.npy")
+    shape, V, psf, its = (64, 64, 64), 3, 9, 3
+    cmd = [sys.executable, os.path.join(root, "tools", "halo_bench.py"), "--size", "64", "64", "64", "--views", str(V),
+           "--psf", str(psf), "--steps", str(its), "--warmup", "0", "--dump-psi", dump]
+    if ranks > 1:
+        cmd += ["--ranks", str(ranks), "--backend", "gloo", "--all-ranks-on-device", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    out = json.loads(line[-1])
+    assert out["n_gpus"] == ranks and out["psi_finite_positive"] and "reference order" in out["config"]["update_mode"]
+    got = np.load(dump)
+    views, k1, k2, w, psi0 = _bench_problem(shape, V, psf)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, its)
+    ref = orc.cpu_deconvolve(psi0, h, 4)  # sequential sweep: the mode has no Jacobi deviation
+    mx, rms = rel_err(got, ref)
+    assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
+
+
 def test_psf_cache_invalidation_on_gpu(gpu, orc):
     # SURVEY.md 8f row 3 on the device: block-after-block calls re-use the resident PSF spectra; the
     # same shape with changed kernel bytes must prepare them again and give the oracle's result

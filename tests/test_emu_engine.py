@@ -92,6 +92,37 @@ def test_walking_rows_kernels_deconvolve_vs_oracle(emu, d2):
     assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-5 * np.sqrt(np.mean(ref ** 2))
 
 
+def test_direct_dim0_halo_mode_on_one_rank(emu, monkeypatch):
+    # HaloSlabDriver with a cyclic self-exchange: the engine hook before every dim0 leg, plane copies in and out of
+    # the halo planes, on the extended slab - against the sequential oracle on the plain volume
+    from libmultiviewnative_amd.sharded import HaloSlabDriver
+    monkeypatch.setenv("MVN_DIM0_DIRECT_MIN_ITEMS", "0")
+    shape, V, ks = (24, 16, 32), 2, (7, 3, 5)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    ref = orc.cpu_deconvolve(psi0, h, 4)
+    drv = HaloSlabDriver(emu, shape, V, ks[0])
+    try:
+        for v in range(V):
+            drv.set_view(v, views[v], w[v], k1[v], k2[v])
+        drv.set_psi(psi0)
+        drv.run(3, 0.006, 1e-4)
+        got = drv.get_psi()
+    finally:
+        drv.close()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    # a PSF deeper than the direct leg takes cannot run in this mode: refused, not computed wrongly
+    _, views, k1, k2, w, psi0 = realistic_views((80, 8, 16), 1, (35, 3, 3))
+    drv = HaloSlabDriver(emu, (80, 8, 16), 1, 35)
+    try:
+        drv.set_view(0, views[0], w[0], k1[0], k2[0])
+        drv.set_psi(psi0)
+        with pytest.raises(Exception):
+            drv.run(1, 0.006, 1e-4)
+    finally:
+        drv.close()
+
+
 def test_packed_nyquist_layout_is_not_used_beyond_its_dim0_limit(emu, monkeypatch):
     # a DC-pair workgroup of the packed layout keeps two dim0 columns in 64 KB of LDS: volumes with more than
     # ~4000 planes keep the separate Nyquist plane (the launch would be refused), forced or not

@@ -131,8 +131,8 @@ MVN_API int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr);
  * calling thread right before every convolution's dim0 leg, with the engine's stream drained: it must fill planes
  * [0, h) and [d0 - h, d0) of `spectrum` ([d0][d1][d2/2] complex, DEVICE memory) with the lower neighbour's last
  * and the upper neighbour's first h own planes; mvn_engine_copy_planes moves whole planes between `spectrum` and
- * an exchange buffer (to_buffer bit 0: spectrum -> buffer; bit 1: the buffer is HOST memory) and returns when the copy
- * is done.  Every PSF must have
+ * an exchange buffer (to_buffer bit 0: spectrum -> buffer; bit 1: the buffer is HOST memory; bit 2: only enqueue the
+ * copy on the engine's stream, do not wait for it).  Every PSF must have
  * at most 33 planes (direct dim0 leg); NULL switches the mode off.  libmultiviewnative_amd/sharded.py drives it. */
 MVN_API int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void* user, void* spectrum, int view, int conv),
                                      void* user);

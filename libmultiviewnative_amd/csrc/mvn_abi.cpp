@@ -1203,7 +1203,7 @@ int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void*, void*, int, int), 
 }
 
 int mvn_engine_copy_planes(mvn_engine* e, void* spectrum, int plane0, int nplanes, void* buffer, int to_buffer) {
-  MVN_ENGINE_CALL("mvn_engine_copy_planes", E.copy_planes(spectrum, plane0, nplanes, buffer, (to_buffer & 1) != 0, (to_buffer & 2) != 0));
+  MVN_ENGINE_CALL("mvn_engine_copy_planes", E.copy_planes(spectrum, plane0, nplanes, buffer, (to_buffer & 1) != 0, (to_buffer & 2) != 0, (to_buffer & 4) == 0));
 }
 
 int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats) {

@@ -1242,7 +1242,8 @@ void Engine::set_halo_hook(halo_fn_t fn, void* user) {
   halo_user_ = user;
 }
 
-void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer) {
+void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer,
+                         bool wait) {
   be::set_device(device_);
   const Layout& L = plan_->L;
   if (!spectrum || !buffer || plane0 < 0 || nplanes < 1 || plane0 + nplanes > L.d0)
@@ -1260,7 +1261,7 @@ void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, 
   } else {
     be::d2d(p, buffer, n, stream_);
   }
-  be::stream_sync(stream_);
+  if (wait) be::stream_sync(stream_);
 }
 
 void Engine::bind_delta(float* external) {

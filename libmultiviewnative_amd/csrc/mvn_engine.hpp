@@ -279,7 +279,8 @@ class Engine {
   // Needs every PSF in the direct form and the packed layout; throws at the first sweep otherwise.
   typedef void (*halo_fn_t)(void* user, void* spectrum, int view, int conv);
   void set_halo_hook(halo_fn_t fn, void* user);
-  void copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer = false);
+  void copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer = false,
+                   bool wait = true);
   float* psi_ptr() { return psi_; }
   size_t volume_floats() const { return plan_->L.real_floats(); }
   // Host stacks of extents `dims` live at offset `off` inside the engine's (larger) volume, the

@@ -403,10 +403,11 @@ class EngineHandle:
         self._halo_cb = self.HALO_FN(lambda user, spectrum, view, conv: fn(spectrum, view, conv))
         self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, C.cast(self._halo_cb, C.c_void_p), None))
 
-    def copy_planes(self, spectrum, plane0, nplanes, buffer_ptr, to_buffer, host_buffer=False):
+    def copy_planes(self, spectrum, plane0, nplanes, buffer_ptr, to_buffer, host_buffer=False, wait=True):
         self.b.check(self.b.l.mvn_engine_copy_planes(self.h, C.c_void_p(spectrum), plane0, nplanes,
                                                      C.c_void_p(buffer_ptr),
-                                                     (1 if to_buffer else 0) | (2 if host_buffer else 0)))
+                                                     (1 if to_buffer else 0) | (2 if host_buffer else 0) |
+                                                     (0 if wait else 4)))
 
     def psi_ptr(self):
         return self._ptr(self.b.l.mvn_engine_psi_ptr)

@@ -232,11 +232,13 @@ class HaloSlabDriver:
         try:
             e, h, nz = self.eng, self.h, self.nz
             hs = self.host_staging
-            e.copy_planes(spectrum, h, h, self.send_lo.data_ptr(), True, hs)    # my first h planes -> lower neighbour
+            e.copy_planes(spectrum, h, h, self.send_lo.data_ptr(), True, hs, wait=False)  # my first h planes -> lower neighbour
             e.copy_planes(spectrum, nz, h, self.send_hi.data_ptr(), True, hs)   # my last h planes  -> upper neighbour
             if self.dist is None:  # one rank: its own neighbour both ways (cyclic)
                 self.recv_hi.copy_(self.send_lo)
                 self.recv_lo.copy_(self.send_hi)
+                if self.send_lo.is_cuda:  # (torch's stream is not the engine's)
+                    self.torch.cuda.synchronize()
             else:
                 d = self.dist
                 lower, upper = (self.rank - 1) % self.world, (self.rank + 1) % self.world
@@ -248,8 +250,10 @@ class HaloSlabDriver:
                     r.wait()
                 if self.send_lo.is_cuda:
                     self.torch.cuda.synchronize()
-            e.copy_planes(spectrum, 0, h, self.recv_lo.data_ptr(), False, hs)
-            e.copy_planes(spectrum, nz + h, h, self.recv_hi.data_ptr(), False, hs)
+            # (the halo planes are read by kernels on the same stream: no wait; host buffers are re-used by the
+            # next exchange, which drains the stream first)
+            e.copy_planes(spectrum, 0, h, self.recv_lo.data_ptr(), False, hs, wait=False)
+            e.copy_planes(spectrum, nz + h, h, self.recv_hi.data_ptr(), False, hs, wait=False)
         except Exception as ex:  # a Python exception cannot cross the C frames of the engine
             self.error = ex
 

@@ -133,9 +133,11 @@ MVN_API int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr);
  * and the upper neighbour's first h own planes; mvn_engine_copy_planes moves whole planes between `spectrum` and
  * an exchange buffer (to_buffer bit 0: spectrum -> buffer; bit 1: the buffer is HOST memory; bit 2: only enqueue the
  * copy on the engine's stream, do not wait for it).  Every PSF must have
- * at most 33 planes (direct dim0 leg); NULL switches the mode off.  libmultiviewnative_amd/sharded.py drives it. */
+ * at most 33 planes (direct dim0 leg); NULL switches the mode off.  drain == 0: `fn` is called WITHOUT waiting for the
+ * stream and must order everything it does on mvn_engine_stream() itself (copies with bit 2, collectives issued with
+ * that stream current): the host then never waits inside a sweep.  libmultiviewnative_amd/sharded.py drives it. */
 MVN_API int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void* user, void* spectrum, int view, int conv),
-                                     void* user);
+                                     void* user, int drain);
 MVN_API int mvn_engine_copy_planes(mvn_engine* e, void* spectrum, int plane0, int nplanes, void* buffer,
                                    int to_buffer);
 MVN_API int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);

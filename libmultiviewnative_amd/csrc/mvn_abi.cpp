@@ -1198,8 +1198,8 @@ int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr) {
   MVN_ENGINE_CALL("mvn_engine_bind_delta", E.bind_delta((float*)dev_ptr));
 }
 
-int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void*, void*, int, int), void* user) {
-  MVN_ENGINE_CALL("mvn_engine_set_halo_hook", E.set_halo_hook(fn, user));
+int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void*, void*, int, int), void* user, int drain) {
+  MVN_ENGINE_CALL("mvn_engine_set_halo_hook", E.set_halo_hook(fn, user, drain != 0));
 }
 
 int mvn_engine_copy_planes(mvn_engine* e, void* spectrum, int plane0, int nplanes, void* buffer, int to_buffer) {

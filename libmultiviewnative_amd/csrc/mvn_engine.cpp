@@ -928,7 +928,7 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
     if (!s.tap_k[i]) throw std::logic_error("mvn: packed Nyquist layout with a kernel that is not in the direct form");
     P.axis1(MVN_ST_FWD, (cfloat*)work_, nullptr, stream_, prof, stream_);
     if (halo_fn_) {  // the neighbours' planes arrive in the halo planes of the leg's input
-      be::stream_sync(stream_);
+      if (halo_drain_) be::stream_sync(stream_);
       halo_fn_(halo_user_, work_, (int)(&s - views_.data()), i);
     }
     ensure_work2();
@@ -1232,7 +1232,7 @@ float* Engine::delta_ptr() {
   return delta_;
 }
 
-void Engine::set_halo_hook(halo_fn_t fn, void* user) {
+void Engine::set_halo_hook(halo_fn_t fn, void* user, bool drain) {
   if (fn) {
     if (!plan_->L.even || !mvn_dim0_packed_possible(plan_->L.d0))
       throw std::invalid_argument("mvn: halo mode needs an even last extent and at most 4062 planes per rank");
@@ -1240,6 +1240,7 @@ void Engine::set_halo_hook(halo_fn_t fn, void* user) {
   }
   halo_fn_ = fn;
   halo_user_ = user;
+  halo_drain_ = drain;
 }
 
 void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer,

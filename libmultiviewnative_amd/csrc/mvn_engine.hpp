@@ -278,7 +278,8 @@ class Engine {
   // Nyquist layout) with the neighbours' planes (copy_planes moves planes between it and exchange buffers).
   // Needs every PSF in the direct form and the packed layout; throws at the first sweep otherwise.
   typedef void (*halo_fn_t)(void* user, void* spectrum, int view, int conv);
-  void set_halo_hook(halo_fn_t fn, void* user);
+  // drain: wait for the stream before calling fn (fn works from the host); false: fn only enqueues work on stream()
+  void set_halo_hook(halo_fn_t fn, void* user, bool drain = true);
   void copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer = false,
                    bool wait = true);
   float* psi_ptr() { return psi_; }
@@ -346,6 +347,7 @@ class Engine {
   bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
   halo_fn_t halo_fn_ = nullptr;
   void* halo_user_ = nullptr;
+  bool halo_drain_ = true;
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;
   int direct_max_taps_ = MVN_D0_MAX_TAPS;

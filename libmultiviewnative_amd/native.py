@@ -123,7 +123,7 @@ class Binding:
         l.mvn_engine_delta_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.mvn_engine_psi_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.mvn_engine_bind_delta.argtypes = [C.c_void_p, C.c_void_p]
-        l.mvn_engine_set_halo_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.mvn_engine_set_halo_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         l.mvn_engine_copy_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         l.mvn_engine_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         l.mvn_engine_sync.argtypes = [C.c_void_p]
@@ -394,14 +394,16 @@ class EngineHandle:
 
     HALO_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 
-    def set_halo_hook(self, fn):
-        """fn(spectrum_ptr, view, conv) before every dim0 leg (mvn_engine_set_halo_hook); None switches it off."""
+    def set_halo_hook(self, fn, drain=True):
+        """fn(spectrum_ptr, view, conv) before every dim0 leg (mvn_engine_set_halo_hook); None switches it off.
+        drain=False: fn is called without waiting for the engine's stream and must order its work on it."""
         if fn is None:
             self._halo_cb = None
-            self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, None, None))
+            self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, None, None, 1))
             return
         self._halo_cb = self.HALO_FN(lambda user, spectrum, view, conv: fn(spectrum, view, conv))
-        self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, C.cast(self._halo_cb, C.c_void_p), None))
+        self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, C.cast(self._halo_cb, C.c_void_p), None,
+                                                       1 if drain else 0))
 
     def copy_planes(self, spectrum, plane0, nplanes, buffer_ptr, to_buffer, host_buffer=False, wait=True):
         self.b.check(self.b.l.mvn_engine_copy_planes(self.h, C.c_void_p(spectrum), plane0, nplanes,

@@ -204,8 +204,14 @@ class HaloSlabDriver:
         # exchange buffers in host memory (gloo has no device send / recv) under an engine on the GPU: the plane
         # copies are device <-> host then; on the host emulation "device" memory is host memory either way
         self.host_staging = (not self.send_lo.is_cuda) and binding.backend_name().startswith("hip")
+        # exchange buffers on the device: everything the exchange does is ORDERED ON THE ENGINE'S STREAM (plane copies
+        # enqueued there, torch copies / send / recv issued with it current, their completion awaited by the stream,
+        # not by the host) and the engine does not drain its stream before calling back - no host wait in a sweep
+        self.ext = None
+        if self.send_lo.is_cuda:
+            self.ext = torch.cuda.ExternalStream(self.eng.stream(), device=dev)
         self.error = None
-        self.eng.set_halo_hook(self._exchange)
+        self.eng.set_halo_hook(self._exchange, drain=self.ext is None)
 
     # --- data in / out: the caller hands over its own planes [z0, z0 + nz) ----------------------------------
     def _extend(self, local, fill):
@@ -230,32 +236,34 @@ class HaloSlabDriver:
         if self.error is not None:
             return
         try:
-            e, h, nz = self.eng, self.h, self.nz
-            hs = self.host_staging
-            e.copy_planes(spectrum, h, h, self.send_lo.data_ptr(), True, hs, wait=False)  # my first h planes -> lower neighbour
-            e.copy_planes(spectrum, nz, h, self.send_hi.data_ptr(), True, hs)   # my last h planes  -> upper neighbour
-            if self.dist is None:  # one rank: its own neighbour both ways (cyclic)
-                self.recv_hi.copy_(self.send_lo)
-                self.recv_lo.copy_(self.send_hi)
-                if self.send_lo.is_cuda:  # (torch's stream is not the engine's)
-                    self.torch.cuda.synchronize()
+            if self.ext is not None:
+                with self.torch.cuda.stream(self.ext):
+                    self._exchange_body(spectrum, False)
             else:
-                d = self.dist
-                lower, upper = (self.rank - 1) % self.world, (self.rank + 1) % self.world
-                # (tags keep the two messages of a pair apart on gloo when lower == upper; the order of the
-                # receives matches the order of the peer's sends for backends that match in issue order)
-                ops = [d.P2POp(d.isend, self.send_lo, lower, tag=0), d.P2POp(d.isend, self.send_hi, upper, tag=1),
-                       d.P2POp(d.irecv, self.recv_hi, upper, tag=0), d.P2POp(d.irecv, self.recv_lo, lower, tag=1)]
-                for r in d.batch_isend_irecv(ops):
-                    r.wait()
-                if self.send_lo.is_cuda:
-                    self.torch.cuda.synchronize()
-            # (the halo planes are read by kernels on the same stream: no wait; host buffers are re-used by the
-            # next exchange, which drains the stream first)
-            e.copy_planes(spectrum, 0, h, self.recv_lo.data_ptr(), False, hs, wait=False)
-            e.copy_planes(spectrum, nz + h, h, self.recv_hi.data_ptr(), False, hs, wait=False)
+                self._exchange_body(spectrum, True)
         except Exception as ex:  # a Python exception cannot cross the C frames of the engine
             self.error = ex
+
+    def _exchange_body(self, spectrum, host_waits):
+        e, h, nz, hs = self.eng, self.h, self.nz, self.host_staging
+        e.copy_planes(spectrum, h, h, self.send_lo.data_ptr(), True, hs, wait=False)        # my first h planes -> lower
+        e.copy_planes(spectrum, nz, h, self.send_hi.data_ptr(), True, hs, wait=host_waits)  # my last h planes -> upper
+        if self.dist is None:  # one rank: its own neighbour both ways (cyclic)
+            self.recv_hi.copy_(self.send_lo)
+            self.recv_lo.copy_(self.send_hi)
+        else:
+            d = self.dist
+            lower, upper = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+            # (tags keep the two messages of a pair apart on gloo when lower == upper; the order of the receives
+            # matches the order of the peer's sends for backends that match in issue order)
+            ops = [d.P2POp(d.isend, self.send_lo, lower, tag=0), d.P2POp(d.isend, self.send_hi, upper, tag=1),
+                   d.P2POp(d.irecv, self.recv_hi, upper, tag=0), d.P2POp(d.irecv, self.recv_lo, lower, tag=1)]
+            for r in d.batch_isend_irecv(ops):
+                r.wait()  # device tensors: the CURRENT stream (the engine's) waits, not the host
+        # (the halo planes are read by kernels on the same stream: no wait; host buffers are re-used by the next
+        # exchange, which drains the stream first)
+        e.copy_planes(spectrum, 0, h, self.recv_lo.data_ptr(), False, hs, wait=False)
+        e.copy_planes(spectrum, nz + h, h, self.recv_hi.data_ptr(), False, hs, wait=False)
 
     def run(self, iterations, lam, min_value):
         self.eng.iterate(iterations, lam, min_value)

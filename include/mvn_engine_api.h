@@ -140,6 +140,22 @@ MVN_API int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void* user, void*
                                      void* user, int drain);
 MVN_API int mvn_engine_copy_planes(mvn_engine* e, void* spectrum, int plane0, int nplanes, void* buffer,
                                    int to_buffer);
+/* Non-finite values in halo mode.  An FFT-based convolution turns ONE Inf / NaN voxel of its input into a volume of
+ * NaN (inc/cpu_convolve.h:256-268), which the update then clamps to minValue everywhere (inc/cpu_kernels.h:40-47,
+ * 76-83).  The direct dim0 leg reproduces that through a 4-byte device word per engine, the "poison word": a leg
+ * that met a non-finite input stores its epoch (the engine's count of direct legs, so the word never needs clearing)
+ * there and the last-axis pass that ends the convolution turns every voxel into NaN when it finds the epoch of its
+ * own convolution.  Slabs of one volume on several engines must agree: with bit 1 of `drain` set in
+ * mvn_engine_set_halo_hook the hook is called a second time per convolution, right after the dim0 leg and the dim1
+ * pass behind it have been enqueued, with conv + 2, and must leave the MAXIMUM of all slabs' words in every slab's
+ * word before it returns / in stream order (epochs only grow and the slabs count in step: the maximum is the latest
+ * report).  _ptr: the word's device address; _bind: make the engine use caller-owned device memory (4 bytes, zeroed;
+ * NULL: back to its own) so that a collective can reduce it in place; _get drains the stream and reads the word;
+ * _merge: word = max(word, value). */
+MVN_API int mvn_engine_poison_ptr(mvn_engine* e, void** dev_ptr);
+MVN_API int mvn_engine_bind_poison(mvn_engine* e, void* dev_ptr);
+MVN_API int mvn_engine_poison_get(mvn_engine* e, unsigned* value);
+MVN_API int mvn_engine_poison_merge(mvn_engine* e, unsigned value);
 MVN_API int mvn_engine_psi_ptr(mvn_engine* e, void** dev_ptr, size_t* n_floats);
 MVN_API int mvn_engine_stream(mvn_engine* e, void** hip_stream);
 MVN_API int mvn_engine_sync(mvn_engine* e);

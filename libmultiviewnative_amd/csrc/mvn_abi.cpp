@@ -280,6 +280,7 @@ static const int kLaneStride = 1024;
 static std::mutex& upload_mutex(int dev) { return device_mutex(2 * kLaneStride + dev); }
 
 static void check_workspace(const imageType* psi, const workspace& input) {
+  if (input.num_views_ < 0) throw std::invalid_argument("num_views_ must be >= 0");
   if (!psi || !input.data_) throw std::invalid_argument("null psi or workspace");
   for (int v = 0; v < input.num_views_; ++v) {  // before anything is dereferenced
     const view_data& d = input.data_[v];
@@ -306,6 +307,7 @@ static void deconvolve_call(imageType* psi, const workspace& input, int device, 
       if (dims[d] < 1) throw std::invalid_argument("image extents must be >= 1");
     shape_t ext = dims;  // padding policy: see the block comment above good_extent()
     int off[3] = {0, 0, 0};
+    bool dim0_kept_exact = false;
     if (pad_mode != MVN_PAD_NONE) {
       for (int d = 2; d >= 0; --d) {
         int kmax = 1;
@@ -320,7 +322,10 @@ static void deconvolve_call(imageType* psi, const workspace& input, int device, 
         // it then keeps the reference's exact image + kernel - 1 (542 planes for a 512-block with 31^3 PSFs, not
         // 576: 6 % less volume in every pass) - provided the rows of a plane keep whole tiles of the fixed
         // last-axis kernels whatever the plane count (d1 a multiple of 16)
-        if (d == 0 && ext[1] % 16 == 0 && Engine::direct_ok_for(kmax, ext[0], ext[1], ext[2])) continue;
+        if (d == 0 && ext[1] % 16 == 0 && Engine::direct_ok_for(kmax, ext[0], ext[1], ext[2])) {
+          dim0_kept_exact = true;
+          continue;
+        }
         ext[d] = good_extent(ext[d], d == 2);
       }
     }
@@ -332,6 +337,21 @@ static void deconvolve_call(imageType* psi, const workspace& input, int device, 
     // on failure the engine is simply dropped
     std::unique_ptr<Engine> eng_owner =
         take_engine(key, dev, ext, V, embedded ? (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2] : 0);
+    if (dim0_kept_exact) {
+      // The static rule above and the engine's own per-kernel decision (Engine::direct_form: also asks that the
+      // tap arrays' plan is of the volume plan's kernel family) must agree, or an exact dim0 such as 542 = 2 * 271
+      // would go through the chirp-z FFT leg: the engine has the last word, dim0 is then padded like the others.
+      bool all = true;
+      for (int v = 0; v < V && all; ++v)
+        all = eng_owner->would_be_direct(input.data_[v].kernel1_dims_) &&
+              eng_owner->would_be_direct(input.data_[v].kernel2_dims_);
+      if (!all) {
+        eng_owner.reset();
+        ext[0] = good_extent(ext[0], false);
+        if (trace_on()) std::printf("[lmvn::trace] direct dim0 leg refused by the engine: dim0 padded to %d\n", ext[0]);
+        eng_owner = take_engine(key, dev, ext, V, (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2]);
+      }
+    }
     Engine& eng = *eng_owner;
     eng.begin_call();
     // stacks are embedded into / cropped out of the padded volume by the transfers themselves
@@ -477,14 +497,18 @@ int mvn_deconvolve_submit(imageType* psi, struct workspace input, int device, lo
       lane = lane_of[dev]++ & 1;
     }
     DeconvJob* j = job.get();
-    {
-      std::lock_guard<std::mutex> lk(jobs_mutex());
-      jobs()[id] = std::move(job);
-    }
+    // (the worker first, the map entry second: a thread that cannot be started leaves no job behind)
     j->worker = std::thread([j, psi, dev, lane, pad_mode] {
       j->rc = guarded("mvn_deconvolve_submit (worker)", [&] { deconvolve_call(psi, j->ws, dev, lane, pad_mode); });
       if (j->rc < 0) j->error = g_last_error;  // the worker's thread-local message travels with the job
     });
+    try {
+      std::lock_guard<std::mutex> lk(jobs_mutex());
+      jobs()[id] = std::move(job);
+    } catch (...) {
+      j->worker.join();
+      throw;
+    }
     *ticket = id;
   });
 }
@@ -1199,7 +1223,29 @@ int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr) {
 }
 
 int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void*, void*, int, int), void* user, int drain) {
-  MVN_ENGINE_CALL("mvn_engine_set_halo_hook", E.set_halo_hook(fn, user, drain != 0));
+  MVN_ENGINE_CALL("mvn_engine_set_halo_hook", E.set_halo_hook(fn, user, (drain & 1) != 0, (drain & 2) != 0));
+}
+
+int mvn_engine_poison_ptr(mvn_engine* e, void** dev_ptr) {
+  MVN_ENGINE_CALL("mvn_engine_poison_ptr", {
+    if (!dev_ptr) throw std::invalid_argument("null argument");
+    *dev_ptr = E.poison_ptr();
+  });
+}
+
+int mvn_engine_bind_poison(mvn_engine* e, void* dev_ptr) {
+  MVN_ENGINE_CALL("mvn_engine_bind_poison", E.bind_poison((unsigned*)dev_ptr));
+}
+
+int mvn_engine_poison_get(mvn_engine* e, unsigned* value) {
+  MVN_ENGINE_CALL("mvn_engine_poison_get", {
+    if (!value) throw std::invalid_argument("null argument");
+    *value = E.poison_get();
+  });
+}
+
+int mvn_engine_poison_merge(mvn_engine* e, unsigned value) {
+  MVN_ENGINE_CALL("mvn_engine_poison_merge", E.poison_merge(value));
 }
 
 int mvn_engine_copy_planes(mvn_engine* e, void* spectrum, int plane0, int nplanes, void* buffer, int to_buffer) {

@@ -212,7 +212,9 @@ static void emu_rows_fused(const RowsParams& p, long ntiles) {
   }
 }
 
-void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int, size_t lds_bytes, stream_t) {
+void launch_rows_c2r_r2c(const RowsParams& p0, long ntiles, int, size_t lds_bytes, stream_t) {
+  RowsParams p = p0;
+  mvn_arm_poison(p.epi);  // (the device kernels do this at their entry)
   if (emu_wave_rows(p, p.epi.mode == MVN_EPI_DIVIDE ? 4 : 8)) return emu_wave_rows_mode<MVN_WR_C2R_R2C>(p);
   if (!p.fixed) {  // run-time-radix form of the fused pass (any even d2)
 #pragma omp parallel
@@ -364,8 +366,10 @@ void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t ld
   }
 }
 
-void launch_rows_c2r(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
+void launch_rows_c2r(const RowsParams& p0, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
+  RowsParams p = p0;
+  mvn_arm_poison(p.epi);
   if (emu_wave_rows(p, p.epi.mode == MVN_EPI_DELTA ? 16 : 2)) return emu_wave_rows_mode<MVN_WR_C2R>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, false)) throw std::invalid_argument("mvn: no fixed kernel");
@@ -427,14 +431,15 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t) {
   switch (mvn_dim0_taps_template(p.k)) {
 #define X(K)                                                                        \
   case K: {                                                                         \
+    const long nblocks = mvn_dim0_blocks(p).blocks;                                 \
     _Pragma("omp parallel for schedule(static)")                                    \
-    for (long g = 0; g < mvn_dim0_items(p); ++g) {                                  \
-      Dim0DirectParams q;                                                           \
-      long b;                                                                       \
-      int zs, nout;                                                                 \
-      if (mvn_dim0_select(p, g, p.stagger > 0 ? (int)(((g / 256) * p.stagger) % p.d0) : 0, q, b, zs, nout)) \
-        mvn_dim0_direct_column<K, MVN_D0_PF>(q, b, zs, nout);                       \
-    }                                                                               \
+    for (long blk = 0; blk < nblocks; ++blk)                                        \
+      for (int t = 0; t < MVN_D0_WG; ++t) {                                         \
+        Dim0DirectParams q;                                                         \
+        long b;                                                                     \
+        int zs, nout;                                                               \
+        if (mvn_dim0_job(p, blk, t, q, b, zs, nout)) mvn_dim0_direct_column<K, MVN_D0_PF>(q, b, zs, nout); \
+      }                                                                             \
   } break;
     MVN_D0_TAP_COUNTS(X)
 #undef X

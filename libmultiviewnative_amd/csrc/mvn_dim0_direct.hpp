@@ -25,6 +25,8 @@
 
 #include "mvn_fft_core.hpp"
 
+#define MVN_D0_MAX_PEERS 7  // further slabs of one volume a launch reports non-finite inputs to
+
 struct Dim0DirectParams {
   const cfloat* in;    // [d0][plane]
   cfloat* out;         // [d0][plane]; must not alias `in`
@@ -59,6 +61,15 @@ struct Dim0DirectParams {
   int packed;
   int C, d1;        // bins per row, rows per plane (plane = d1 * C)
   const int* inv1;  // inv1[k1] = row that holds bin k1 along dim1 (position order, AxisPlan::inv)
+  // Non-finite inputs (see mvn_dim0_track): a work item that met one stores `poison_epoch` into *poison, and the
+  // last-axis pass that ends this convolution (EpilogueParams::poison) then emits NaN for EVERY voxel - what an FFT
+  // along dim0 would have made of it.  The epoch is the engine's count of direct legs, so the word is never cleared.
+  // A device that runs one slab of a volume reports to every slab's word: poison_peers = a device table of
+  // n_peers (<= MVN_D0_MAX_PEERS) further words - the other devices', written through peer access.
+  unsigned* poison;
+  unsigned poison_epoch;
+  int n_peers;
+  unsigned* const* poison_peers;
 };
 
 #define MVN_D0_PF 4         // planes requested ahead
@@ -83,6 +94,32 @@ MVN_HD cfloat mvn_cmac(cfloat acc, cfloat a, cfloat w) {
 #endif
 }
 
+// Non-finite values.  The RL loop lets NaN / Inf flow (0 / 0 and x / 0 quotients, inc/cpu_kernels.h:19-26)
+// and an FFT-based convolution turns ONE such voxel into a volume of NaN (inc/cpu_convolve.h:256-268), which
+// the update then clamps to minValue everywhere (inc/cpu_kernels.h:40-47,76-83) - the reference's, and the
+// oracle's, behaviour.  A direct convolution along dim0 would only spoil the K planes around the voxel.  The
+// last-axis and dim1 transforms have already spread the voxel over its whole plane when this pass runs, so
+// every column - and every piece of a column whose tracked planes include that plane - meets a non-finite
+// input: it REPORTS it (mvn_dim0_report), and the last-axis pass that ends the convolution reads the report
+// once per workgroup and turns every voxel into NaN (mvn_arm_poison, mvn_pass_bodies.hpp).  Whole columns,
+// pieces, the Nyquist pieces and the packed DC-pair workgroups therefore all end in the same volume, the one
+// the FFT leg would have left.
+// bad += 0 * v, one packed fused multiply-add: 0 * finite = (+-)0, 0 * Inf = 0 * NaN = NaN; bad != 0 afterwards
+// exactly when a non-finite value came by
+MVN_HD cfloat mvn_dim0_track(cfloat bad, cfloat v) {
+#if defined(MVN_PACKED)
+  cfloat r;
+  asm("v_pk_fma_f32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(bad));
+  return r;
+#else
+  return cmake(bad.x + 0.f * v.x, bad.y + 0.f * v.y);
+#endif
+}
+MVN_HD void mvn_dim0_report(const Dim0DirectParams& P) {
+  if (P.poison) *P.poison = P.poison_epoch;  // (same value from every work item that gets here: a plain store)
+  for (int i = 0; i < P.n_peers; ++i) *P.poison_peers[i] = P.poison_epoch;
+}
+
 // pairs (k1, -k1) of the packed DC column
 inline int mvn_dim0_pairs(int d1) { return d1 / 2 + 1; }
 // LDS of a DC-pair workgroup (two columns of d0 values + two sets of k taps) and the longest dim0 it allows:
@@ -98,10 +135,14 @@ MVN_HD void mvn_dim0_dc_load(const Dim0DirectParams& P, int pair, cfloat* lds, i
   cfloat* b = lds + P.d0;
   cfloat* U = lds + 2 * (long)P.d0;
   cfloat* V = U + P.k;
+  cfloat bad = cmake(0.f, 0.f);
   for (int z = tid; z < P.d0; z += nthreads) {
-    a[z] = P.in[(long)z * P.plane + ra];
-    b[z] = P.in[(long)z * P.plane + rb];
+    const cfloat va = P.in[(long)z * P.plane + ra], vb = P.in[(long)z * P.plane + rb];
+    a[z] = va;
+    b[z] = vb;
+    bad = mvn_dim0_track(mvn_dim0_track(bad, va), vb);
   }
+  if (bad.x != 0.f || bad.y != 0.f) mvn_dim0_report(P);
   for (int j = tid; j < P.k; j += nthreads) {
     int p = j - P.h;
     p = p < 0 ? p + P.kd : p;
@@ -133,42 +174,55 @@ MVN_HD void mvn_dim0_dc_compute(const Dim0DirectParams& P, int pair, const cfloa
   }
 }
 
-// work item `g` of a launch: the arrays it belongs to, the bin it owns there and the output planes
-// [z0, z0 + nout) it produces (cyclically)
-MVN_HD bool mvn_dim0_select(const Dim0DirectParams& P, long g, int wg_start, Dim0DirectParams& Q, long& b, int& z0,
-                            int& nout) {
+// Workgroups of a launch (MVN_D0_WG work items each).  A workgroup takes MVN_D0_WG neighbouring bins of ONE piece of
+// ONE set of arrays, so that the planes it walks - and with them every address computation of the walk - are the
+// same for all its lanes: they live in scalar registers and cost no vector instructions (round 4: with per-lane
+// planes the 64-bit multiplies of the addresses took more vector cycles than the K complex multiply-adds).
+// Order: the main array piece by piece (a plane's bins in address order), then the second set likewise.
+#define MVN_D0_WG 256
+struct Dim0Blocks {
+  long nb1, nb2;       // workgroups per piece (bins of a plane / MVN_D0_WG, rounded up)
+  int seg1, seg2;      // output planes per piece
+  long main_blocks;    // nb1 * pieces of the main array
+  long blocks;         // all of them
+};
+MVN_HD Dim0Blocks mvn_dim0_blocks(const Dim0DirectParams& P) {
+  Dim0Blocks B;
+  B.seg1 = P.seg1 > 0 ? P.seg1 : P.d0;
+  B.seg2 = P.seg2 > 0 ? P.seg2 : P.d0;
+  B.nb1 = (P.plane + MVN_D0_WG - 1) / MVN_D0_WG;
+  B.nb2 = (P.packed || P.plane2 <= 0) ? 0 : (P.plane2 + MVN_D0_WG - 1) / MVN_D0_WG;
+  B.main_blocks = B.nb1 * ((P.d0 + B.seg1 - 1) / B.seg1);
+  B.blocks = B.main_blocks + B.nb2 * ((P.d0 + B.seg2 - 1) / B.seg2);  // (+ mvn_dim0_pairs(d1) workgroups when packed)
+  return B;
+}
+// workgroup `block`, lane `tid`: the arrays (Q), the bin b the lane owns there and the output planes
+// [z0, z0 + nout) (cyclically) of the workgroup; false: the lane has nothing to do
+MVN_HD bool mvn_dim0_job(const Dim0DirectParams& P, long block, int tid, Dim0DirectParams& Q, long& b, int& z0,
+                         int& nout) {
+  const Dim0Blocks B = mvn_dim0_blocks(P);
   Q = P;
-  const int seg1 = P.seg1 > 0 ? P.seg1 : P.d0;
-  const long main_items = P.plane * ((P.d0 + seg1 - 1) / seg1);
-  if (g < main_items) {
-    const long piece = g / P.plane;
-    b = g - piece * P.plane;
-    if (P.packed && b % P.C == 0) return false;  // the packed DC column belongs to the pair workgroups
-    z0 = P.seg1 > 0 ? (int)(piece * seg1) : wg_start;
-    nout = P.seg1 > 0 ? (P.d0 - z0 < seg1 ? P.d0 - z0 : seg1) : P.d0;
-    return true;
+  if (block < B.main_blocks) {
+    const long piece = block / B.nb1;
+    b = (block - piece * B.nb1) * MVN_D0_WG + tid;
+    // whole columns: workgroups start their cyclic walk at different planes (all of them on one plane at a time
+    // keep the whole chip on 1 MB in and 1 MB out)
+    z0 = P.seg1 > 0 ? (int)(piece * B.seg1) : (P.stagger > 0 ? (int)((block * P.stagger) % P.d0) : 0);
+    nout = P.seg1 > 0 ? (P.d0 - z0 < B.seg1 ? P.d0 - z0 : B.seg1) : P.d0;
+    if (b >= P.plane) return false;
+    return !(P.packed && b % P.C == 0);  // the packed DC column belongs to the pair workgroups
   }
-  if (P.plane2 <= 0 || P.packed) return false;
-  const long g2 = g - main_items;
-  const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
-  const long piece = g2 / P.plane2;
-  b = g2 - piece * P.plane2;
-  z0 = (int)(piece * seg);
-  if (z0 >= P.d0) return false;
-  nout = P.d0 - z0 < seg ? P.d0 - z0 : seg;
+  if (B.nb2 == 0) return false;
+  const long block2 = block - B.main_blocks;
+  const long piece = block2 / B.nb2;
+  b = (block2 - piece * B.nb2) * MVN_D0_WG + tid;
+  z0 = (int)(piece * B.seg2);
+  nout = P.d0 - z0 < B.seg2 ? P.d0 - z0 : B.seg2;
   Q.in = P.in2;
   Q.out = P.out2;
   Q.taps = P.taps2;
   Q.plane = P.plane2;
-  return true;
-}
-// work items of a launch
-inline long mvn_dim0_items(const Dim0DirectParams& P) {
-  const int seg1 = P.seg1 > 0 ? P.seg1 : P.d0;
-  const long main_items = P.plane * ((P.d0 + seg1 - 1) / seg1);
-  if (P.packed) return main_items;  // + mvn_dim0_pairs(P.d1) workgroups, see the launchers
-  const int seg = P.seg2 > 0 ? P.seg2 : P.d0;
-  return main_items + (P.plane2 > 0 ? P.plane2 * ((P.d0 + seg - 1) / seg) : 0);
+  return z0 < P.d0 && b < P.plane2;
 }
 // Piece length for the main columns of a (d0, plane) volume: as many pieces as bring a launch to `want` work
 // items, but none shorter than 2 K + 8 planes (every piece reads its K + 3 window planes again); 0 = whole
@@ -191,39 +245,104 @@ template <int K, int PF>
 struct Dim0Window {
   cfloat w[K + PF];
   cfloat tap[K];
-  cfloat bad;  // sum of (x - x) over every input of the column: 0, or NaN once a non-finite value came by
+  cfloat bad;  // sum of (x - x) over the tracked inputs: 0, or NaN once a non-finite value came by
 };
 
-// Non-finite values.  The RL loop lets NaN / Inf flow (0 / 0 and x / 0 quotients, inc/cpu_kernels.h:19-26)
-// and an FFT-based convolution turns ONE such voxel into a volume of NaN, which the update then clamps to
-// minValue everywhere (inc/cpu_kernels.h:76-80) - the reference's, and the oracle's, behaviour.  The last-axis
-// and dim1 transforms have already spread the voxel over its whole plane when this pass runs, so every column
-// meets a non-finite input: a column that did rewrites ALL its outputs as NaN, and the volume comes out as
-// the FFT leg would have left it.
-MVN_HD cfloat mvn_dim0_track(cfloat bad, cfloat v) { return cadd(bad, csub(v, v)); }
+
+// The walk of a workgroup: the plane being written (z) and the plane being requested (znew) with their addresses,
+// all the same for every lane and advanced by additions (scalar registers, no multiplies inside the walk); what
+// varies per lane is the 32-bit bin index b alone.
+struct Dim0Walk {
+  const cfloat* in0;   // plane 0 of the input
+  cfloat* out0;        // plane 0 of the output
+  const cfloat* pin;   // plane znew of the input
+  cfloat* pout;        // plane z of the output
+  long plane;
+  unsigned bytes;      // of a plane
+  int z, znew, d0;
+};
+MVN_HD void mvn_dim0_advance(Dim0Walk& w) {
+  ++w.znew;
+  w.pin += w.plane;
+  if (w.znew == w.d0) {
+    w.znew = 0;
+    w.pin = w.in0;
+  }
+  ++w.z;
+  w.pout += w.plane;
+  if (w.z == w.d0) {
+    w.z = 0;
+    w.pout = w.out0;
+  }
+}
+
+// Element at byte offset `boff` (32 bits, the lane's part) of the plane at `p` (the workgroup's part).  On the
+// device as a BUFFER access - the plane's address in a scalar resource descriptor, the lane's offset in one vector
+// register - so that walking from plane to plane is two scalar additions and no vector instruction at all (a flat
+// 64-bit address per lane would be rebuilt with vector adds and selects at every step).  `bytes` = extent of a
+// plane: lanes beyond it read 0 / write nothing.
+// values that are the same in every lane of a workgroup, said so to the compiler (they then live in scalar registers)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MVN_HOST_EMU)
+MVN_HD int mvn_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+MVN_HD long mvn_uniform(long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v & 0xffffffffu));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v >> 32));
+  return (long)(((unsigned long)hi << 32) | lo);
+}
+#else
+MVN_HD int mvn_uniform(int v) { return v; }
+MVN_HD long mvn_uniform(long v) { return v; }
+#endif
+template <typename T>
+MVN_HD T* mvn_uniform(T* p) { return reinterpret_cast<T*>(mvn_uniform(reinterpret_cast<long>(p))); }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MVN_HOST_EMU)
+MVN_HD cfloat mvn_dim0_ld(const cfloat* p, unsigned boff, unsigned bytes) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b64(r, (int)boff, 0, 0);
+}
+MVN_HD void mvn_dim0_st(cfloat* p, unsigned boff, unsigned bytes, cfloat v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)boff, 0, 0);
+}
+#else
+MVN_HD cfloat mvn_dim0_ld(const cfloat* p, unsigned boff, unsigned) {
+  return *reinterpret_cast<const cfloat*>(reinterpret_cast<const char*>(p) + boff);
+}
+MVN_HD void mvn_dim0_st(cfloat* p, unsigned boff, unsigned, cfloat v) {
+  *reinterpret_cast<cfloat*>(reinterpret_cast<char*>(p) + boff) = v;
+}
+#endif
 
 template <int K, int PF, int U>
-MVN_HD void mvn_dim0_step(Dim0Window<K, PF>& r, const cfloat* __restrict__ in, cfloat* __restrict__ out, long plane,
-                          int d0, int nout, int nn, int& z, int& znew) {
+MVN_HD void mvn_dim0_step(Dim0Window<K, PF>& r, Dim0Walk& w, unsigned b, int nout, int nn) {
   constexpr int KW = K + PF;
   if (nn + U >= nout) return;  // nout outputs in all, the walk is cyclic
   cfloat acc = cmake(0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < K; ++j) acc = mvn_cmac(acc, r.w[(j + PF - U + KW) % KW], r.tap[j]);
-  out[(long)z * plane] = acc;
+  mvn_dim0_st(w.pout, b, w.bytes, acc);
   // x_0 = in[z + h] runs over every plane of the column once: tracked HERE, where it has long arrived
   // (at its load the check would stall on the request that was just issued)
   r.bad = mvn_dim0_track(r.bad, r.w[(PF - U + KW) % KW]);
   // the oldest value x_{K-1} leaves; in[z + h + PF + 1], x_{-PF} of the next step, takes its slot
-  r.w[(K - 1 + PF - U + KW) % KW] = in[(long)znew * plane];
-  znew = znew + 1 == d0 ? 0 : znew + 1;
-  z = z + 1 == d0 ? 0 : z + 1;
-  if constexpr (U + 1 < KW) mvn_dim0_step<K, PF, U + 1>(r, in, out, plane, d0, nout, nn, z, znew);
+  r.w[(K - 1 + PF - U + KW) % KW] = mvn_dim0_ld(w.pin, b, w.bytes);
+  mvn_dim0_advance(w);
+  if constexpr (U + 1 < KW) mvn_dim0_step<K, PF, U + 1>(r, w, b, nout, nn);
 }
 
-// outputs [z0, z0 + nout) (cyclically) of bin b
+// outputs [z0, z0 + nout) (cyclically) of bin b_ (< 2^28: checked at the launch)
 template <int K, int PF>
-MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P, long b, int z0, int nout) {
+MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P0, long b_, int z0_, int nout_) {
+  // everything but b_ is the workgroup's (mvn_dim0_job)
+  Dim0DirectParams P = P0;
+  P.in = mvn_uniform(P0.in);
+  P.out = mvn_uniform(P0.out);
+  P.taps = mvn_uniform(P0.taps);
+  P.plane = mvn_uniform(P0.plane);
+  const int z0 = mvn_uniform(z0_), nout = mvn_uniform(nout_);
+  const unsigned b = (unsigned)b_ * (unsigned)sizeof(cfloat);  // byte offset inside a plane
+  const unsigned bytes = (unsigned)P.plane * (unsigned)sizeof(cfloat);
   constexpr int KW = K + PF;
   Dim0Window<K, PF> r;
   r.bad = cmake(0.f, 0.f);
@@ -231,32 +350,30 @@ MVN_HD void mvn_dim0_direct_column(const Dim0DirectParams& P, long b, int z0, in
   for (int j = 0; j < K; ++j) {
     int p = j - P.h;
     p = p < 0 ? p + P.kd : p;
-    r.tap[j] = j < P.k ? P.taps[(long)p * P.plane + b] : cmake(0.f, 0.f);
+    r.tap[j] = j < P.k ? mvn_dim0_ld(P.taps + (long)p * P.plane, b, bytes) : cmake(0.f, 0.f);
   }
   // at u = 0 (z = z0): slot s holds x_{s - PF} = in[z0 + h + PF - s]
 #pragma unroll
   for (int s = 0; s < KW; ++s) {
     int z = z0 + P.h + PF - s;
     z = z < 0 ? z + P.d0 : (z >= P.d0 ? z - P.d0 : z);
-    r.w[s] = P.in[(long)z * P.plane + b];
+    r.w[s] = mvn_dim0_ld(P.in + (long)z * P.plane, b, bytes);
   }
-  int znew = z0 + P.h + PF + 1;
-  if (znew >= P.d0) znew -= P.d0;
-  int zout = z0;
-  // (in and out never alias: the leg is out of place)
-  const cfloat* __restrict__ in = P.in + b;
-  cfloat* __restrict__ out = P.out + b;
-  for (int nn = 0; nn < nout; nn += KW) mvn_dim0_step<K, PF, 0>(r, in, out, P.plane, P.d0, nout, nn, zout, znew);
-  if (r.bad.x != 0.f || r.bad.y != 0.f) {  // (NaN != 0): see mvn_dim0_track
-    const float q = r.bad.x != 0.f ? r.bad.x : r.bad.y;
-    // (whole columns - the main array's - thereby turn NaN entirely, which is what makes the volume come out
-    // all NaN after the passes that follow; a PIECE of a column rewrites its own outputs only)
-    int z = z0;
-    for (int n = 0; n < nout; ++n) {
-      P.out[(long)z * P.plane + b] = cmake(q, q);
-      z = z + 1 == P.d0 ? 0 : z + 1;
-    }
-  }
+  Dim0Walk w;
+  w.in0 = P.in;
+  w.out0 = P.out;  // (in and out never alias: the leg is out of place)
+  w.plane = P.plane;
+  w.bytes = bytes;
+  w.d0 = P.d0;
+  w.znew = z0 + P.h + PF + 1;
+  if (w.znew >= P.d0) w.znew -= P.d0;
+  w.z = z0;
+  w.pin = P.in + (long)w.znew * P.plane;
+  w.pout = P.out + (long)w.z * P.plane;
+  for (int nn = 0; nn < nout; nn += KW) mvn_dim0_step<K, PF, 0>(r, w, b, nout, nn);
+  // (NaN != 0): the tracked planes of this work item - in[z + h] for each of its outputs z, so the pieces of a
+  // column between them see every plane exactly once - held a non-finite value
+  if (r.bad.x != 0.f || r.bad.y != 0.f) mvn_dim0_report(P);
 }
 
 // the instantiated tap counts, for the launch switches of both backends

@@ -196,6 +196,11 @@ static bool ax0_fixed(const Layout& L) {
 
 Plan3D::Plan3D(int dev, int d0, int d1, int d2)
     : device(dev), L(d0, d1, d2), ax2(L.h, rows_fixed(L)), ax1(d1, ax1_fixed(L)), ax0(d0, ax0_fixed(L)) {
+  // the word an epilogue that follows no direct dim0 leg compares with (EpilogueParams::poison is never null
+  // on the device): zero, against the epoch 0xffffffff no leg ever has
+  no_poison = (unsigned*)be::dmalloc(64);
+  be::dzero(no_poison, 64, nullptr);
+  be::stream_sync(nullptr);
   if (L.even) {
     std::vector<cfloat> roots((size_t)L.h / 2 + 1);
     for (size_t k = 0; k < roots.size(); ++k) {
@@ -244,7 +249,10 @@ Plan3D::Plan3D(int dev, int d0, int d1, int d2)
   }
 }
 
-Plan3D::~Plan3D() { be::dfree(twr); }
+Plan3D::~Plan3D() {
+  be::dfree(twr);
+  be::dfree(no_poison);
+}
 
 // a range of rows of a last-axis pass: whole tiles where the kernels need them
 static long rows_in_range(const Plan3D& P, long row0, long nrows) {
@@ -325,6 +333,10 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   p.nyq_packed = (L.even && !in_nyq) ? 1 : 0;
   p.out_real = out_real;
   p.epi = epi;
+  if (!p.epi.poison) {
+    p.epi.poison = no_poison;
+    p.epi.poison_epoch = 0xffffffffu;
+  }
   ProfScope ps(prof, KK_ROWS_C2R, s);
   if (fx_rows) {
     p.fixed = 1;
@@ -354,6 +366,10 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, 
   p.out_nyq = nyq;
   p.nyq_packed = nyq ? 0 : 1;
   p.epi = epi;
+  if (!p.epi.poison) {
+    p.epi.poison = no_poison;
+    p.epi.poison_epoch = 0xffffffffu;
+  }
   ProfScope ps(prof, epi.mode == MVN_EPI_UPDATE ? KK_ROWS_FUSED_UPD : KK_ROWS_FUSED, s);
   if (fx_rows) {
     p.fixed = 1;
@@ -606,6 +622,9 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   be::dzero(psi_, mb, stream_);
   be::dzero(work_, mb, stream_);
   if (plan_->nyq_bytes()) work_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
+  poison_own_ = (unsigned*)be::dmalloc(256);  // the word, and at byte 64 the table of the peers' words
+  be::dzero(poison_own_, 256, stream_);
+  poison_ = poison_own_;
   views_.resize((size_t)num_views);
   spec_tiled_ = plan_->tiles_spectra();
   // read per engine (A/B runs, tests).  MVN_DIM0_DIRECT_MAX: most PSF planes the direct dim0 leg takes on
@@ -657,6 +676,7 @@ Engine::~Engine() {
   be::dfree(psi_spec_);
   be::dfree(psi_spec_nyq_);
   be::dfree(embed_scratch_);
+  be::dfree(poison_own_);
   be::graph_destroy(sweep_graph_);
   if (!delta_external_) be::dfree(delta_);
   try {
@@ -798,6 +818,7 @@ void Engine::prepare_psf(ViewSlot& s, int i, const float* d_kernel, const int* k
     const int D = d == 0 ? L.d0 : (d == 1 ? L.d1 : L.d2);
     if (kdims[d] < 1 || kdims[d] > D) throw std::invalid_argument("mvn: kernel extent must be in [1, image extent]");
   }
+  ++graph_gen_;  // a captured sweep holds the PSF buffers, their form and depth
   if (direct_form(kdims)) {
     const int kd = ((kdims[0] + 1 + 15) / 16) * 16;
     Plan3D* tp = taps_plan(kd);
@@ -869,6 +890,16 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   p.seg1 = mvn_dim0_piece_len(p.k, L.d0, p.plane, direct_min_plane_);
   p.C = L.C;
   p.d1 = L.d1;
+  // non-finite inputs are reported under this leg's epoch (never 0, never a value the word may still hold)
+  if (++epoch_ == 0x7fffffffu) {
+    be::dzero(poison_, sizeof(unsigned), stream_);
+    epoch_ = 1;
+  }
+  armed_epoch_ = epoch_;
+  p.poison = poison_;
+  p.poison_epoch = epoch_;
+  p.n_peers = (int)poison_peers_.size();
+  p.poison_peers = (unsigned* const*)(poison_own_ + 16);
   if (packed_) {
     p.packed = 1;
     p.taps2 = s.taps_nyq[i];
@@ -892,6 +923,48 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   be::launch_dim0_direct(p, stream_);
 }
 
+void Engine::arm(EpilogueParams& e) {
+  e.poison = armed_epoch_ ? poison_ : nullptr;
+  e.poison_epoch = armed_epoch_;
+  armed_epoch_ = 0;
+}
+
+void Engine::bind_poison(unsigned* external) {
+  be::set_device(device_);
+  be::stream_sync(stream_);
+  be::graph_destroy(sweep_graph_);  // a captured sweep holds the word's address
+  sweep_graph_ = nullptr;
+  poison_ = external ? external : poison_own_;
+  be::dzero(poison_own_, sizeof(unsigned), stream_);
+  be::stream_sync(stream_);
+}
+
+unsigned Engine::poison_get() {
+  be::set_device(device_);
+  unsigned v = 0;
+  be::d2h(&v, poison_, sizeof(v), stream_);
+  be::stream_sync(stream_);
+  return v;
+}
+
+// word = max(word, value): epochs only grow, so the larger one is the later report
+void Engine::poison_merge(unsigned value) {
+  if (value > poison_get()) {
+    be::h2d(poison_, &value, sizeof(value), stream_);
+    be::stream_sync(stream_);  // (`value` is a stack variable)
+  }
+}
+
+void Engine::add_poison_peer(unsigned* word) {
+  if (!word) throw std::invalid_argument("mvn: null poison word");
+  if ((int)poison_peers_.size() >= MVN_D0_MAX_PEERS) throw std::invalid_argument("mvn: too many poison peers");
+  be::set_device(device_);
+  be::stream_sync(stream_);
+  poison_peers_.push_back(word);
+  be::h2d(poison_own_ + 16, poison_peers_.data(), poison_peers_.size() * sizeof(unsigned*), stream_);
+  be::stream_sync(stream_);
+}
+
 // every view's two kernels are held in the direct form: the Nyquist bins can ride in the DC column
 bool Engine::all_direct() const {
   if (views_.empty()) return false;
@@ -902,7 +975,9 @@ bool Engine::all_direct() const {
 
 void Engine::decide_layout() {
   const bool want = packed_allowed_ && plan_->L.even && plan_->nyq_bytes() > 0;
+  const bool was = packed_;
   packed_ = want && (pipelined_ ? packed_hint_ : all_direct());
+  if (was != packed_) ++graph_gen_;  // ... and the layout
 }
 
 bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
@@ -936,6 +1011,10 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
     std::swap(work_, work2_);
     std::swap(work_nyq_, work2_nyq_);
     P.axis1(MVN_ST_INV, (cfloat*)work_, nullptr, stream_, prof, stream_);
+    if (halo_fn_ && halo_post_) {  // the slabs merge their reports of non-finite inputs under the dim1 pass
+      if (halo_drain_) be::stream_sync(stream_);
+      halo_fn_(halo_user_, work_, (int)(&s - views_.data()), i + 2);
+    }
     return;
   }
   if (halo_fn_)
@@ -1145,6 +1224,7 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   if (!work_has_psi_spectrum_) P.rows_r2c(psi_, (cfloat*)work_, wn(), stream_, prof);
   work_has_psi_spectrum_ = false;
   middle(s, 0, prof, side);
+  arm(e1);
   // view / blurred, handed to convolution 2 as its last-axis spectrum
   if (fuse) {
     P.rows_c2r_r2c((cfloat*)work_, wn(), e1, stream_, prof);
@@ -1154,6 +1234,7 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   }
   // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
   middle(s, 1, prof, side);
+  arm(e2);
   if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
     P.rows_c2r_r2c((cfloat*)work_, wn(), e2, stream_, prof);
     work_has_psi_spectrum_ = true;
@@ -1190,14 +1271,18 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
     }
     if (use_graph && it >= 1 && it < iterations - 1) {
       if (sweep_graph_ && (graph_lambda_ != lambda || graph_min_ != min_value ||
-                           graph_guard_ != quotient_guard_)) {
+                           graph_guard_ != quotient_guard_ || graph_captured_gen_ != graph_gen_ ||
+                           graph_work_ != work_)) {
         be::graph_destroy(sweep_graph_);
         sweep_graph_ = nullptr;
       }
       if (!sweep_graph_) {
         // all views were used by sweep 0, so none is still being staged
+        const float* work_at_capture = work_;
         be::capture_begin(stream_);
         try {
+          // (a replay reports under the epochs of the capture: the word must not still hold one of them)
+          be::dzero(poison_, sizeof(unsigned), stream_);
           for (int v = 0; v < V; ++v) conv_pair(v, lambda, min_value, MVN_EPI_UPDATE, 0, true);
         } catch (...) {
           try {
@@ -1210,6 +1295,8 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
         graph_lambda_ = lambda;
         graph_min_ = min_value;
         graph_guard_ = quotient_guard_;
+        graph_captured_gen_ = graph_gen_;
+        graph_work_ = work_at_capture;  // (the two work volumes swap roles at every direct leg)
       }
       be::graph_launch(sweep_graph_, stream_);
       continue;
@@ -1232,7 +1319,7 @@ float* Engine::delta_ptr() {
   return delta_;
 }
 
-void Engine::set_halo_hook(halo_fn_t fn, void* user, bool drain) {
+void Engine::set_halo_hook(halo_fn_t fn, void* user, bool drain, bool post) {
   if (fn) {
     if (!plan_->L.even || !mvn_dim0_packed_possible(plan_->L.d0))
       throw std::invalid_argument("mvn: halo mode needs an even last extent and at most 4062 planes per rank");
@@ -1241,6 +1328,7 @@ void Engine::set_halo_hook(halo_fn_t fn, void* user, bool drain) {
   halo_fn_ = fn;
   halo_user_ = user;
   halo_drain_ = drain;
+  halo_post_ = post && fn;
 }
 
 void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer,
@@ -1383,6 +1471,7 @@ void Engine::compute_delta_head(double lambda, float min_value) {
     }
     P.axis1(MVN_ST_INV, (cfloat*)work_, wn(), stream_, prof, sn);
     if (use_side) side_.join_into(stream_);
+    arm(e1);
     if (fuse) {
       P.rows_c2r_r2c((cfloat*)work_, wn(), e1, stream_, prof);
     } else {
@@ -1390,6 +1479,7 @@ void Engine::compute_delta_head(double lambda, float min_value) {
       P.rows_r2c(work_, (cfloat*)work_, wn(), stream_, prof);
     }
     middle(s, 1, prof, use_side ? &side_ : nullptr);
+    arm(e2);
     if (v + 1 < V) {
       P.rows_c2r((const cfloat*)work_, wn(), psi_, e2, stream_, prof);
     } else {  // the last view's final pass is launched chunk by chunk (compute_delta_chunk)

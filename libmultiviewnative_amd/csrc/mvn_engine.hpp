@@ -104,6 +104,7 @@ class Plan3D {
   const Layout L;
   DevAxis ax2, ax1, ax0;
   cfloat* twr = nullptr;  // d2-th roots of unity (even d2)
+  unsigned* no_poison = nullptr;  // a zero word: what EpilogueParams::poison points to after an FFT dim0 leg
   PassGeom g_rows, g_ax1, g_ax0, g_ax0f, g_nyq1, g_nyq0;
   // compile-time specialised kernels (mvn_fixed.hpp) are used where the shape allows
   bool fx_rows = false, fx_ax1 = false, fx_ax0 = false;
@@ -279,7 +280,22 @@ class Engine {
   // Needs every PSF in the direct form and the packed layout; throws at the first sweep otherwise.
   typedef void (*halo_fn_t)(void* user, void* spectrum, int view, int conv);
   // drain: wait for the stream before calling fn (fn works from the host); false: fn only enqueues work on stream()
-  void set_halo_hook(halo_fn_t fn, void* user, bool drain = true);
+  // post: fn is called a second time right AFTER the leg has been enqueued, with conv + 2 - where the ranks merge
+  // their poison words (a non-finite input met by ONE slab's leg must turn EVERY slab's volume into NaN)
+  void set_halo_hook(halo_fn_t fn, void* user, bool drain = true, bool post = false);
+  // The poison word (mvn_dim0_direct.hpp, EpilogueParams::poison): a direct dim0 leg that met a non-finite input
+  // stores its epoch there.  poison_ptr(): the device word; bind_poison(): use caller-owned device memory (4 bytes,
+  // zeroed) instead, e.g. a torch tensor a collective can MAX-reduce in place; poison_get() drains the stream and
+  // reads it; poison_merge(v): word = max(word, v), enqueued on stream(); add_poison_peer(): a further word (another
+  // slab's, reachable from this device) every report is also written to.
+  unsigned* poison_ptr() { return poison_; }
+  void bind_poison(unsigned* external);
+  unsigned poison_get();
+  void poison_merge(unsigned value);
+  void add_poison_peer(unsigned* word);
+  void clear_poison_peers() { poison_peers_.clear(); }  // (the device table is only read up to n_peers)
+  // slabs of one volume on several engines count their direct legs together: same epoch for the same leg
+  unsigned poison_epoch() const { return epoch_; }
   void copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer = false,
                    bool wait = true);
   float* psi_ptr() { return psi_; }
@@ -347,7 +363,14 @@ class Engine {
   bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
   halo_fn_t halo_fn_ = nullptr;
   void* halo_user_ = nullptr;
-  bool halo_drain_ = true;
+  bool halo_drain_ = true, halo_post_ = false;
+  unsigned* poison_ = nullptr;      // the word in use: poison_own_, or caller-owned memory (bind_poison)
+  unsigned* poison_own_ = nullptr;  // 256 bytes: [0] the engine's own word, byte 64: table of the peers' words
+  std::vector<unsigned*> poison_peers_;
+  unsigned epoch_ = 0;        // direct dim0 legs enqueued so far = the epoch of the latest
+  unsigned armed_epoch_ = 0;  // != 0: the convolution in flight ran a direct leg with this epoch
+  // hands the report of the convolution's direct leg (if it had one) to the last-axis pass that ends it
+  void arm(EpilogueParams& e);
   bool direct_enabled_ = true;
   int d0_stagger_ = 0;
   int direct_max_taps_ = MVN_D0_MAX_TAPS;
@@ -395,6 +418,10 @@ class Engine {
   double graph_lambda_ = 0;
   float graph_min_ = 0;
   bool graph_guard_ = false;
+  // PSF preparations and layout changes so far / at capture: the graph bakes in the PSF buffers, their form
+  // (taps or 3-D spectrum), depth and the Nyquist layout
+  unsigned long graph_gen_ = 0, graph_captured_gen_ = 0;
+  const float* graph_work_ = nullptr;  // which of the two work volumes was current when the sweep was captured
   std::vector<ViewSlot> views_;
   Profiler prof_;
 };

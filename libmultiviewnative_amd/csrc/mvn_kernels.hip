@@ -97,8 +97,10 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_r2c(const RowsParams
 }
 
 template <int H, int EPI>
-__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams p) {
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams p0) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  RowsParams p = p0;
+  mvn_arm_poison(p.epi);
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
   fx_rows_run<H, 1, EPI>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
@@ -107,8 +109,10 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams
 // (The divide form needs 93 VGPRs, just above the 84 that would let three 512-thread workgroups
 // share a CU; forcing it there with a waves-per-SIMD bound spilled 56 bytes and gained nothing.)
 template <int H, int EPI>
-__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p) {
+__global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p0) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  RowsParams p = p0;
+  mvn_arm_poison(p.epi);
   FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
   fx_rows_run<H, 2, EPI>(p, (long)MVN_PROBE_TILE(blockIdx.x), (long)gridDim.x, (cfloat*)mvn_smem, ctx);
@@ -117,8 +121,10 @@ __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsPa
 // last-axis passes for d2 = 512 in which a row never leaves its half-wave (mvn_wave_rows.hpp): no
 // workgroup barrier inside the loop over rows, 4 LDS exchanges per fused pass
 template <int MODE, int EPI>
-__global__ void __launch_bounds__(WrCfg::NT, 4) kw_rows(const RowsParams p) {
+__global__ void __launch_bounds__(WrCfg::NT, 4) kw_rows(const RowsParams p0) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  RowsParams p = p0;
+  if (MODE != MVN_WR_R2C) mvn_arm_poison(p.epi);
   FxCtx<WrRegs, WrCfg::NT> ctx;
   ctx.tid = (int)threadIdx.x;
   wr_rows_body<MODE, EPI>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
@@ -142,25 +148,22 @@ __global__ void __launch_bounds__((FxSplitCfg<N>::NT)) kx_strided_split(const St
 }
 
 // direct dim0 convolution (mvn_dim0_direct.hpp): one bin per work item, all of dim0
+// (K = 25 sits one register above the 128 that let four waves share a SIMD: bounded there)
 template <int K, int PF = MVN_D0_PF>
-__global__ void __launch_bounds__(256) kd_dim0(const Dim0DirectParams p, unsigned main_blocks) {
+__global__ void __launch_bounds__(MVN_D0_WG, (K == 25 ? 4 : 1)) kd_dim0(const Dim0DirectParams p, unsigned main_blocks) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   if (blockIdx.x >= main_blocks) {  // packed Nyquist: one (k1, -k1) pair of the DC column per workgroup
     const int pair = (int)(blockIdx.x - main_blocks);
-    mvn_dim0_dc_load(p, pair, (cfloat*)mvn_smem, (int)threadIdx.x, 256);
+    mvn_dim0_dc_load(p, pair, (cfloat*)mvn_smem, (int)threadIdx.x, MVN_D0_WG);
     __syncthreads();
-    mvn_dim0_dc_compute(p, pair, (const cfloat*)mvn_smem, (int)threadIdx.x, 256);
+    mvn_dim0_dc_compute(p, pair, (const cfloat*)mvn_smem, (int)threadIdx.x, MVN_D0_WG);
     return;
   }
-  // workgroups start their cyclic walk along dim0 at different planes (p.stagger): all of them on one
-  // plane at a time keep the whole chip on 1 MB in and 1 MB out
-  const int z0 = p.stagger > 0 ? (int)(((long)blockIdx.x * p.stagger) % p.d0) : 0;
   Dim0DirectParams q;
   long b;
   int zs, nout;
-  // (the main plane is a multiple of the workgroup size in every fixed-kernel layout; a workgroup that
-  // straddles the boundary just has lanes on both sets of arrays)
-  if (mvn_dim0_select(p, (long)blockIdx.x * 256 + threadIdx.x, z0, q, b, zs, nout))
+  // (zs, nout and the arrays in q depend on the workgroup only: scalar registers)
+  if (mvn_dim0_job(p, (long)blockIdx.x, (int)threadIdx.x, q, b, zs, nout))
     mvn_dim0_direct_column<K, PF>(q, b, zs, nout);
 }
 
@@ -744,7 +747,8 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
       p.plane2 < 0 || (p.plane2 > 0 && (!p.in2 || !p.out2 || !p.taps2 || p.in2 == p.out2)))
     throw std::invalid_argument("mvn: direct dim0 convolution called outside its range");
   if (p.plane > 0) check_aligned16(p.in, "input");  // (8-byte accesses; the volumes are 16-byte aligned anyway)
-  const long main_blocks = (mvn_dim0_items(p) + 255) / 256;
+  if (p.plane + p.plane2 >= (1L << 28)) throw std::invalid_argument("mvn: plane too large for the direct dim0 leg");
+  const long main_blocks = mvn_dim0_blocks(p).blocks;
   long nblocks = main_blocks;
   size_t lds = 0;
   if (p.packed) {
@@ -756,7 +760,7 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
   }
   if (nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
   switch (mvn_dim0_taps_template(p.k)) {
-#define X(K) case K: hipLaunchKernelGGL(kd_dim0<K>, dim3((unsigned)nblocks), dim3(256), lds, hs(s), p, (unsigned)main_blocks); break;
+#define X(K) case K: hipLaunchKernelGGL(kd_dim0<K>, dim3((unsigned)nblocks), dim3(MVN_D0_WG), lds, hs(s), p, (unsigned)main_blocks); break;
     MVN_D0_TAP_COUNTS(X)
 #undef X
     default: throw std::invalid_argument("mvn: no direct dim0 kernel for this tap count");

@@ -48,7 +48,25 @@ struct EpilogueParams {
   int guard_zero_view;  // DIVIDE: a view voxel that is exactly 0 gives quotient 0 even where the
                         // blurred estimate is 0 (0 * 1/0 = NaN otherwise); only set for the
                         // good-size zero-padding mode, whose extra zeros lie beyond the PSF's reach
+  // The convolution this pass ends ran its dim0 leg as a direct convolution (mvn_dim0_direct.hpp), which stores
+  // `poison_epoch` into *poison when its input held a non-finite value: the whole volume then has to come out
+  // NaN, as it does through an FFT along dim0 (inc/cpu_convolve.h:256-268).  No such leg: a zero word and the
+  // epoch 0xffffffff (Plan3D::no_poison) - the pointer is never null when a pass is launched.
+  const unsigned* poison;
+  unsigned poison_epoch;
 };
+
+// Once per workgroup, before the first epilogue: a reported non-finite input turns the scale every raw output is
+// multiplied with first into NaN - and with it every voxel (DIVIDE: view * 1 / NaN; UPDATE / DELTA: the clamp
+// chain maps NaN to minValue) - at no cost per element.
+MVN_HD void mvn_arm_poison(EpilogueParams& e) {
+  // (no branch, and selected as an integer: the word, the epoch and the scale are the same for every lane, and an integer
+  // select of scalars stays in a scalar register where a float select would move the scale into a vector one)
+  unsigned bits;
+  __builtin_memcpy(&bits, &e.scale, sizeof(bits));
+  bits = *e.poison == e.poison_epoch ? 0x7fc00000u : bits;
+  __builtin_memcpy(&e.scale, &bits, sizeof(bits));
+}
 
 // quotient with the optional guard above
 MVN_HD float mvn_quotient_g(float view, float blurred, int guard);
@@ -335,6 +353,10 @@ MVN_HD void rows_r2c_even_body(const RowsParams& P, long tile, int tid, int nthr
 // forward half (rows_r2c_even_tail), writing the half-spectrum of the result over the input.
 template <int T, bool KEEP = false>
 MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
+  // (a copy of the epilogue's few fields, not of P: the run-time radix tables in P are indexed dynamically and a
+  // private copy of the whole struct would live in scratch memory)
+  EpilogueParams epi = P.epi;
+  mvn_arm_poison(epi);
   constexpr int U = MVN_ROWS_U;
   const int h = P.h, TP = P.TP;
   const long r0 = tile * T;
@@ -364,7 +386,7 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
       v[u] = P.in_cplx[row * P.C + k];
       idx[u] = row * P.RP + 2 * k;
     }
-    if (single) mvn_epilogue_fetch_batch<U>(P.epi, idx, ea, eb);
+    if (single) mvn_epilogue_fetch_batch<U>(epi, idx, ea, eb);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int w = w0 + u * nthreads;
@@ -412,7 +434,7 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
         row = row < last_row ? row : last_row;
         idx[u] = row * P.RP + 2 * j;
       }
-      mvn_epilogue_fetch_batch<U>(P.epi, idx, ea, eb);
+      mvn_epilogue_fetch_batch<U>(epi, idx, ea, eb);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -421,10 +443,10 @@ MVN_HD void rows_c2r_even_body(const RowsParams& P, long tile, int tid, int nthr
       const long row = r0 + rho;
       if (w < total && row <= last_row) {
         if (KEEP)
-          buf[j * TP + rho] = mvn_epilogue_pair_value(P.epi.mode, P.epi, row * P.RP + 2 * j,
+          buf[j * TP + rho] = mvn_epilogue_pair_value(epi.mode, epi, row * P.RP + 2 * j,
                                                       buf[j * TP + rho], ea[u], eb[u]);
         else
-          mvn_epilogue_pair(P.epi, P.out_real, row * P.RP + 2 * j, buf[j * TP + rho], ea[u], eb[u]);
+          mvn_epilogue_pair(epi, P.out_real, row * P.RP + 2 * j, buf[j * TP + rho], ea[u], eb[u]);
       }
     }
   }
@@ -460,6 +482,10 @@ MVN_HD void rows_r2c_odd_body(const RowsParams& P, long tile, int tid, int nthre
 
 template <int T>
 MVN_HD void rows_c2r_odd_body(const RowsParams& P, long tile, int tid, int nthreads, cfloat* lds) {
+  // (a copy of the epilogue's few fields, not of P: the run-time radix tables in P are indexed dynamically and a
+  // private copy of the whole struct would live in scratch memory)
+  EpilogueParams epi = P.epi;
+  mvn_arm_poison(epi);
   const int n = P.h, TP = P.TP;
   const long r0 = tile * T;
   cfloat* buf = lds;
@@ -484,7 +510,7 @@ MVN_HD void rows_c2r_odd_body(const RowsParams& P, long tile, int tid, int nthre
   for (int w = tid; w < T * n; w += nthreads) {
     const int rho = (int)mvn_fastdiv((unsigned)w, (unsigned)n, P.hmul), j = w - rho * n;
     const long row = r0 + rho;
-    if (row < P.rows) mvn_epilogue(P.epi, P.out_real, row * P.RP + j, buf[j * TP + rho].x);
+    if (row < P.rows) mvn_epilogue(epi, P.out_real, row * P.RP + j, buf[j * TP + rho].x);
   }
 }
 

@@ -36,7 +36,7 @@ ENGINE_ABI_SYMBOLS = [
     "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
     "mvn_engine_delta_chunks", "mvn_engine_delta_chunk_range", "mvn_engine_compute_delta_head",
     "mvn_engine_compute_delta_chunk", "mvn_engine_apply_delta_chunk",
-    "mvn_engine_bind_delta", "mvn_engine_set_halo_hook", "mvn_engine_copy_planes", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
+    "mvn_engine_bind_delta", "mvn_engine_set_halo_hook", "mvn_engine_poison_ptr", "mvn_engine_bind_poison", "mvn_engine_poison_get", "mvn_engine_poison_merge", "mvn_engine_copy_planes", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
     "mvn_engine_profile", "mvn_engine_profile_read", "mvn_kernel_kind_count",
     "mvn_kernel_kind_name", "mvn_engine_B",
     "mvn_slab_create", "mvn_slab_destroy", "mvn_slab_set_view", "mvn_slab_set_psi", "mvn_slab_get_psi",
@@ -125,6 +125,10 @@ class Binding:
         l.mvn_engine_bind_delta.argtypes = [C.c_void_p, C.c_void_p]
         l.mvn_engine_set_halo_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         l.mvn_engine_copy_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        l.mvn_engine_poison_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        l.mvn_engine_bind_poison.argtypes = [C.c_void_p, C.c_void_p]
+        l.mvn_engine_poison_get.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+        l.mvn_engine_poison_merge.argtypes = [C.c_void_p, C.c_uint]
         l.mvn_engine_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         l.mvn_engine_sync.argtypes = [C.c_void_p]
         l.mvn_engine_time_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_float,
@@ -394,16 +398,28 @@ class EngineHandle:
 
     HALO_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 
-    def set_halo_hook(self, fn, drain=True):
+    def set_halo_hook(self, fn, drain=True, post=False):
         """fn(spectrum_ptr, view, conv) before every dim0 leg (mvn_engine_set_halo_hook); None switches it off.
-        drain=False: fn is called without waiting for the engine's stream and must order its work on it."""
+        drain=False: fn is called without waiting for the engine's stream and must order its work on it.
+        post=True: fn is called again behind the leg with conv + 2, where the slabs merge their poison words."""
         if fn is None:
             self._halo_cb = None
             self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, None, None, 1))
             return
         self._halo_cb = self.HALO_FN(lambda user, spectrum, view, conv: fn(spectrum, view, conv))
         self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, C.cast(self._halo_cb, C.c_void_p), None,
-                                                       1 if drain else 0))
+                                                       (1 if drain else 0) | (2 if post else 0)))
+
+    def bind_poison(self, dev_ptr):
+        self.b.check(self.b.l.mvn_engine_bind_poison(self.h, C.c_void_p(dev_ptr)))
+
+    def poison_get(self):
+        v = C.c_uint(0)
+        self.b.check(self.b.l.mvn_engine_poison_get(self.h, C.byref(v)))
+        return v.value
+
+    def poison_merge(self, value):
+        self.b.check(self.b.l.mvn_engine_poison_merge(self.h, C.c_uint(int(value))))
 
     def copy_planes(self, spectrum, plane0, nplanes, buffer_ptr, to_buffer, host_buffer=False, wait=True):
         self.b.check(self.b.l.mvn_engine_copy_planes(self.h, C.c_void_p(spectrum), plane0, nplanes,

@@ -176,7 +176,18 @@ class HaloSlabDriver:
     image 1 / weights 0 and whatever the passes leave in them; before every dim0 leg the engine calls back
     (``mvn_engine_set_halo_hook``) and the planes of the neighbours overwrite the halo planes of the leg's input.
     Every PSF must have at most 33 planes along dim0 and ``nz >= h``.  Built and parity-tested on gloo ranks
-    (CPU emulation) and on one GPU; un-measured on several GPUs (the exchange here is synchronous).
+    (CPU emulation) and on one GPU; un-measured on several GPUs.  With device exchange buffers everything the
+    exchange does is ordered on the engine's stream (the host never waits inside a sweep); with host buffers
+    (gloo) it is synchronous.
+
+    Non-finite values: the reference's FFT convolution turns one Inf / NaN voxel into a volume of NaN.  A slab's
+    direct leg reports such an input in its engine's poison word (``mvn_engine_api.h``); behind every leg the
+    hook is called a second time and the ranks MAX-reduce their words (4 bytes), so that every slab's last-axis
+    pass floods its part of the volume.
+
+    A failed exchange cannot raise through the engine's C frames: the rank records the error, keeps taking part
+    in the remaining exchanges (so that its peers do not block in a receive that never gets matched), and
+    ``run()`` raises on EVERY rank once the sweep is over (the ranks all-reduce an error flag).
     """
 
     def __init__(self, binding, full_shape, num_views, max_psf_depth, dist=None, rank=0, world=1, device=0,
@@ -211,7 +222,12 @@ class HaloSlabDriver:
         if self.send_lo.is_cuda:
             self.ext = torch.cuda.ExternalStream(self.eng.stream(), device=dev)
         self.error = None
-        self.eng.set_halo_hook(self._exchange, drain=self.ext is None)
+        # the poison word: a 1-element int32 tensor the collective can reduce in place (device path), or the
+        # engine's own word read / merged through the host (host buffers)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.ext is not None:
+            self.eng.bind_poison(self.flag.data_ptr())
+        self.eng.set_halo_hook(self._exchange, drain=self.ext is None, post=self.dist is not None)
 
     # --- data in / out: the caller hands over its own planes [z0, z0 + nz) ----------------------------------
     def _extend(self, local, fill):
@@ -233,16 +249,27 @@ class HaloSlabDriver:
 
     # --- the exchange, called by the engine before every dim0 leg ------------------------------------------------
     def _exchange(self, spectrum, view, conv):
-        if self.error is not None:
-            return
+        # (after an error this rank goes on exchanging - whatever its planes hold - so that its peers' receives
+        # and collectives stay matched; run() raises on every rank at the end)
         try:
+            body = self._merge_poison if conv >= 2 else self._exchange_body
             if self.ext is not None:
                 with self.torch.cuda.stream(self.ext):
-                    self._exchange_body(spectrum, False)
+                    body(spectrum, False)
             else:
-                self._exchange_body(spectrum, True)
+                body(spectrum, True)
         except Exception as ex:  # a Python exception cannot cross the C frames of the engine
-            self.error = ex
+            if self.error is None:
+                self.error = ex
+
+    def _merge_poison(self, spectrum, host_waits):
+        d = self.dist
+        if self.ext is not None:  # the bound word itself, in stream order
+            d.all_reduce(self.flag, op=d.ReduceOp.MAX)
+            return
+        self.flag[0] = self.eng.poison_get()
+        d.all_reduce(self.flag, op=d.ReduceOp.MAX)
+        self.eng.poison_merge(int(self.flag[0]))
 
     def _exchange_body(self, spectrum, host_waits):
         e, h, nz, hs = self.eng, self.h, self.nz, self.host_staging
@@ -268,9 +295,18 @@ class HaloSlabDriver:
     def run(self, iterations, lam, min_value):
         self.eng.iterate(iterations, lam, min_value)
         self.eng.sync()
+        failed = self.error is not None
+        if self.dist is not None:  # a rank whose exchange failed makes every rank raise
+            t = self.torch.tensor([1 if failed else 0], dtype=self.torch.int32, device=self.flag.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            failed = int(t[0]) != 0
         if self.error is not None:
             raise self.error
+        if failed:
+            raise RuntimeError("halo mode: the exchange failed on another rank")
 
     def close(self):
         self.eng.set_halo_hook(None)
+        if self.ext is not None:
+            self.eng.bind_poison(None)
         self.eng.close()

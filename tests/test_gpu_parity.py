@@ -34,6 +34,20 @@ def orc():
     return binding
 
 
+# The suite pins the direct dim0 leg to large planes (tests/conftest.py) so that the many small-shape cases keep
+# validating the fused FFT dim0 pass; a host program gets the PRODUCT DEFAULTS - the direct leg at every size,
+# columns cut into pieces, the Nyquist bins packed into the DC column.  Tests that take this fixture run under
+# both.  The switches are read per engine / per call: cached engines are dropped either side.
+@pytest.fixture(params=["suite pin", "product defaults"])
+def leg(request, gpu, monkeypatch):
+    if request.param == "product defaults":
+        monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_ITEMS", raising=False)
+        monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_PLANE", raising=False)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    yield request.param
+    gpu.check(gpu.l.mvn_release_cached_engines())
+
+
 def rel_err(got, ref):
     d = got.astype(np.float64) - ref.astype(np.float64)
     return (np.abs(d).max() / max(np.abs(ref).max(), 1e-30),
@@ -337,7 +351,7 @@ def test_pointwise_entry_points_bit_exact(gpu, orc):
                                                  ((8, 12, 10), (3, 3, 3), 1, 5),
                                                  ((64, 64, 64), (9, 9, 9), 3, 10),
                                                  ((48, 60, 40), (7, 11, 5), 6, 4)])
-def test_deconvolve_vs_oracle(gpu, orc, shape, kshape, nv, its, lam):
+def test_deconvolve_vs_oracle(gpu, orc, shape, kshape, nv, its, lam, leg):
     _, views, k1, k2, w, psi0 = realistic_views(shape, nv, kshape)
     h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, its)
     got = gpu.gpu_deconvolve(psi0, h)
@@ -348,7 +362,7 @@ def test_deconvolve_vs_oracle(gpu, orc, shape, kshape, nv, its, lam):
     assert float(((got.astype(np.float64) - ref) ** 2).sum()) < 1
 
 
-def test_baseline_config0_64cubed(gpu, orc):
+def test_baseline_config0_64cubed(gpu, orc, leg):
     # BASELINE.json configs[0]: 64^3, 1 view, 3^3 PSF, 5 iterations (reference synthetic data)
     shape = (64, 64, 64)
     views, k1, k2, w = synthetic_views(shape, 1, 3, 3)
@@ -361,7 +375,7 @@ def test_baseline_config0_64cubed(gpu, orc):
     assert np.abs(got - 29.40588).max() < 2e-4 * 29.40588
 
 
-def test_baseline_config1_256cubed_vs_oracle(gpu, orc):
+def test_baseline_config1_256cubed_vs_oracle(gpu, orc, leg):
     # BASELINE.json configs[1]: 256^3, 1 view, 15^3 Gaussian PSF, 10 iterations; oracle on all cores
     from ref_fixtures import gaussian_psf
     shape = (256, 256, 256)
@@ -426,7 +440,7 @@ def test_full_size_config5_closed_form(gpu):
     assert np.abs(psi - want).max() < 2e-4 * want
 
 
-def test_loop_invariants(gpu, orc):
+def test_loop_invariants(gpu, orc, leg):
     shape = (16, 16, 16)
     views, k1, k2, w = synthetic_views(shape, 3, 3, 5)
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-3, 2)
@@ -465,7 +479,7 @@ def test_device_minus_one_autoselects(gpu, orc):
 
 
 @pytest.mark.parametrize("shape", [(24, 20, 28), (64, 64, 128)])
-def test_simultaneous_mode_vs_oracle(gpu, orc, shape):
+def test_simultaneous_mode_vs_oracle(gpu, orc, shape, leg):
     _, views, k1, k2, w, psi0 = realistic_views(shape, 4, (5, 5, 5))
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
     eng = gpu.engine(shape, 4)
@@ -531,7 +545,7 @@ def _zero_padd_reference(orc, psi0, views, k1, k2, w, lam, minv, its):
     return orc.cpu_deconvolve(embed(psi0), h, 4)[sl]
 
 
-def test_zero_padd_mode_matches_reference_gpu_policy(gpu, orc, monkeypatch):
+def test_zero_padd_mode_matches_reference_gpu_policy(gpu, orc, monkeypatch, leg):
     shape = (20, 16, 24)
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, (5, 3, 7))
     k2[1] = k2[1][:3]  # kernels of different extents: the policy takes the maxima
@@ -549,7 +563,7 @@ def test_zero_padd_mode_matches_reference_gpu_policy(gpu, orc, monkeypatch):
     monkeypatch.delenv("MVN_PAD_MODE")
 
 
-def test_zero_padd_good_size_mode(gpu, orc, monkeypatch):
+def test_zero_padd_good_size_mode(gpu, orc, monkeypatch, leg):
     # The library's DEFAULT policy (the reference GPU entry's zero_padd, src/multiviewnative.cu:
     # 26-27,128) with FFT-friendly padded extents: they grow to 2^a 3^b 5^c 7^d (here 19+5-1=23 -> 24,
     # 13+3-1=15, 17+7-1=23 -> 24) and the quotient is guarded where the view is exactly 0.
@@ -635,7 +649,7 @@ def test_degenerate_inputs(gpu, capfd):
 
 
 @pytest.mark.parametrize("name", ["identity", "horizont", "vertical", "depth", "all1"])
-def test_golden_fixture_a(gpu, name):
+def test_golden_fixture_a(gpu, name, leg):
     # committed golden vectors (tests/golden/fixture_a.npz): the reference's fixture and its
     # FFT-independent expectations
     from golden_util import fixture_a
@@ -646,7 +660,7 @@ def test_golden_fixture_a(gpu, name):
 
 
 @pytest.mark.parametrize("lam", [0.0, 0.006])
-def test_golden_rl_small(gpu, lam):
+def test_golden_rl_small(gpu, lam, leg):
     # committed RL vectors computed by the float64 numpy restatement (independent of the C oracle)
     from golden_util import rl_small
     psi0, h, seq, sim = rl_small(lam)
@@ -780,52 +794,65 @@ def test_slab_engine_one_rank_equals_resident_engine(gpu, shape, V):
     assert mx <= MAX_REL and rms <= RMS_REL, (mx, rms)
 
 
-_GRAPH_CHILD = r"""
+# (shared by the child, which replays captured sweeps, and the parent, which launches directly)
+_GRAPH_RUNS = r"""
+def graph_runs(lib, shape, np, realistic_views):
+    V, its = 3, 6
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (5, 5, 5), seed=12)
+    e = lib.engine(shape, V)
+    for v in range(V):
+        e.set_view(v, views[v], w[v], k1[v], k2[v])
+    out = []
+    for lam in (0.006, 0.0, 0.0):      # second and third: re-capture on a parameter change, then re-use
+        e.set_psi(psi0); e.iterate(its, lam, 1e-4); e.sync(); out.append(e.get_psi())
+    # one Inf voxel: the flooded convolutions of a replayed sweep report under the epochs of the capture
+    bad = psi0.copy(); bad[shape[0] // 2, 3, 3] = np.inf
+    e.set_psi(bad); e.iterate(its, 0.0, 1e-4); e.sync(); out.append(e.get_psi())
+    e.set_psi(psi0); e.iterate(its, 0.0, 1e-4); e.sync(); out.append(e.get_psi())  # and a clean run behind it
+    # other PSFs of another depth on the same engine (ADVICE r03: the captured sweep holds the PSF buffers,
+    # their form and their depth - it has to be captured again)
+    _, _, k1b, k2b, _, _ = realistic_views(shape, V, (3, 5, 5), seed=13)
+    for v in range(V):
+        e.set_view(v, views[v], w[v], k1b[v], k2b[v])
+    e.set_psi(psi0); e.iterate(its, 0.0, 1e-4); e.sync(); out.append(e.get_psi())
+    e.close()
+    return np.stack(out)
+"""
+
+_GRAPH_CHILD = _GRAPH_RUNS + r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
 from libmultiviewnative_amd import native
 from ref_fixtures import realistic_views
-shape = tuple(int(x) for x in sys.argv[3:6]); V, its = 3, 6
-_, views, k1, k2, w, psi0 = realistic_views(shape, V, (5, 5, 5), seed=12)
-lib = native.lib()
-e = lib.engine(shape, V)
-for v in range(V):
-    e.set_view(v, views[v], w[v], k1[v], k2[v])
-out = []
-for lam in (0.006, 0.0, 0.0):      # second and third: re-capture on a parameter change, then re-use
-    e.set_psi(psi0); e.iterate(its, lam, 1e-4); e.sync(); out.append(e.get_psi())
-e.close()
-np.save(sys.argv[2], np.stack(out))
+shape = tuple(int(x) for x in sys.argv[3:6])
+np.save(sys.argv[2], graph_runs(native.lib(), shape, np, realistic_views))
 """
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(32, 32, 32), (64, 64, 128), (24, 20, 18)])
-def test_graph_replayed_sweeps_equal_direct_launches(gpu, shape, tmp_path):
+def test_graph_replayed_sweeps_equal_direct_launches(gpu, shape, tmp_path, leg):
     # MVN_GRAPH=1 (opt-in): sweeps 2..n-1 of a call are replayed from a captured graph on small
     # volumes (Engine::iterate).  A child process runs with it, this process with direct launches;
-    # same kernels in the same order, so the results must be bit-identical.
+    # same kernels in the same order, so the results must be bit-identical - with the fused FFT dim0 pass
+    # (suite pin) and with the direct leg in pieces + packed Nyquist layout (product defaults), through a
+    # non-finite voxel and across a change of PSF depth on the same engine.
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "graph.npy")
-    env = dict(os.environ, MVN_GRAPH="1")
+    env = dict(os.environ, MVN_GRAPH="1")  # (the fixture has already set / removed the pins in os.environ)
     subprocess.run([sys.executable, "-c", _GRAPH_CHILD, root, out] + [str(x) for x in shape],
                    check=True, env=env, timeout=300)
     got = np.load(out)
-    V, its = 3, 6
-    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (5, 5, 5), seed=12)
-    e = gpu.engine(shape, V)
-    for v in range(V):
-        e.set_view(v, views[v], w[v], k1[v], k2[v])
-    for i, lam in enumerate((0.006, 0.0, 0.0)):
-        e.set_psi(psi0)
-        e.iterate(its, lam, 1e-4)
-        e.sync()
-        ref = e.get_psi()
-        assert np.all(np.isfinite(ref))
-        assert np.array_equal(got[i], ref)
-    e.close()
+    ns = {}
+    exec(_GRAPH_RUNS, ns)
+    ref = ns["graph_runs"](gpu, shape, np, realistic_views)
+    assert got.shape == ref.shape == (6,) + tuple(shape)
+    for i in range(6):
+        assert np.isfinite(ref[i]).sum() >= ref[i].size - 1, i  # (run 3 keeps its one NaN voxel)
+        assert np.array_equal(got[i], ref[i], equal_nan=True), i
+    assert not np.array_equal(ref[4], ref[5])  # the other PSFs were really used
 
 
 @pytest.mark.gpu
@@ -1002,7 +1029,7 @@ def test_full_size_config4_one_view_vs_oracle(gpu, orc):
 
 
 @pytest.mark.parametrize("shape,chunks", [((64, 64, 64), 4), ((24, 20, 18), 3), ((12, 10, 9), 5)])
-def test_chunked_simultaneous_steps_vs_oracle(gpu, orc, shape, chunks):
+def test_chunked_simultaneous_steps_vs_oracle(gpu, orc, shape, chunks, leg):
     # the overlapped form of the sharded step on one rank, several iterations with the spectrum of
     # psi handed from apply_delta_chunk to the next compute_delta_head
     from libmultiviewnative_amd.sharded import SimultaneousDriver
@@ -1144,7 +1171,7 @@ def test_psf_cache_invalidation_on_gpu(gpu, orc):
     gpu.check(gpu.l.mvn_release_cached_engines())
 
 
-def test_default_padding_policy_on_a_block(gpu, orc):
+def test_default_padding_policy_on_a_block(gpu, orc, leg):
     # the library default (zero_padd with FFT-friendly extents): a 50 x 60 x 70 block with 9^3 / 7^3
     # PSFs runs on a padded 64-ish volume and is cropped back; oracle on hand-padded stacks, guard on
     shape = (50, 60, 70)
@@ -1320,6 +1347,30 @@ def test_direct_dim0_leg_in_a_child_process(gpu, direct):
             env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD, root], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "direct child ok " + direct[0] in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("env", [{}, {"MVN_NYQ_PACKED": "0"}, {"MVN_DIM0_DIRECT_MIN_PLANE": "250"}],
+                         ids=["product defaults", "split nyquist", "short pieces"])
+def test_nonfinite_voxel_floods_the_volume_in_every_form_of_the_direct_leg(gpu, monkeypatch, env):
+    # one Inf voxel in the middle of a PIECE of a column (the product default below 512 x 512
+    # planes), in psi and in a view, sequential and simultaneous, 1 and 2 iterations, WITHOUT the suite's pins -
+    # identical to the oracle (whose FFT convolution floods the volume, inc/cpu_convolve.h:256-268).  The leg
+    # reports the value in the engine's poison word and the last-axis pass that ends the convolution emits NaN.
+    from nonfinite_util import nonfinite_cases
+    monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_ITEMS", raising=False)
+    monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_PLANE", raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    try:
+        cases = [((192, 16, 32), (5, 3, 3), (100, 5, 5)), ((256, 16, 32), (5, 3, 3), (100, 5, 5)),
+                 ((64, 10, 12), (5, 3, 3), (5, 5, 5))]
+        if not env:
+            cases.append(((256, 256, 256), (15, 15, 15), (100, 50, 60)))  # BASELINE configs[1]'s shape: 4 pieces
+        for shape, kshape, pos in cases:
+            nonfinite_cases(gpu, shape, kshape, pos, nviews=1 if shape[1] == 256 else 2)
+    finally:
+        gpu.check(gpu.l.mvn_release_cached_engines())
 
 
 def test_default_policy_keeps_dim0_exact_under_the_direct_leg(gpu, orc, monkeypatch):

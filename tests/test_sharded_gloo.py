@@ -188,7 +188,13 @@ def test_two_rank_slab_sweep_matches_sequential(tmp_path, case):
 
 # ---- dim0 slabs with halo exchange (HaloSlabDriver): the reference's update order on several ranks ---------------
 HALO_CASES = {"two_ranks": ((24, 16, 32), 2, 2, (7, 3, 5)), "four_ranks_even_depth": ((32, 16, 32), 2, 4, (4, 5, 3)),
-              "three_ranks_deep_psf": ((48, 32, 16), 1, 3, (15, 3, 3))}
+              "three_ranks_deep_psf": ((48, 32, 16), 1, 3, (15, 3, 3)),
+              # one Inf voxel of psi in the middle of rank 0's slab, beyond the reach of its neighbours' halos, and rank 2
+              # is not even a neighbour: the reference's FFT convolution floods the WHOLE volume
+              # (inc/cpu_convolve.h:256-268), so the ranks have to tell each other (poison word, MAX-reduced behind
+              # every dim0 leg; without that rank 2 gets an ordinary update from view 0)
+              "four_ranks_inf_voxel": ((64, 16, 32), 2, 4, (5, 3, 3))}
+HALO_INF_AT = (7, 5, 5)
 HALO_ITS = 3
 
 
@@ -205,6 +211,8 @@ def _halo_worker(rank, world, port, out_dir, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     shape, V, _, ks = HALO_CASES[case]
     _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks)
+    if "inf_voxel" in case:
+        psi0[HALO_INF_AT] = np.inf
     emu = native.Binding(native.EMU_SO)
     drv = HaloSlabDriver(emu, shape, V, ks[0], dist=dist, rank=rank, world=world)
     sl = slice(drv.z0, drv.z0 + drv.nz)
@@ -230,7 +238,12 @@ def test_halo_slab_sweep_matches_the_sequential_oracle(tmp_path, case):
     mp.spawn(_halo_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("halo_rank%d.npy" % r)) for r in range(world)], axis=0)
     _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks)
+    if "inf_voxel" in case:
+        psi0[HALO_INF_AT] = np.inf
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, HALO_ITS)
     ref = orc.cpu_deconvolve(psi0, h, 2)  # the reference's own (sequential) order: no Jacobi deviation
     assert got.shape == ref.shape
+    if "inf_voxel" in case:  # every update is the exact minValue blend (the voxel itself stays NaN): bit-equal
+        assert np.isnan(ref).sum() == 1 and np.array_equal(got, ref, equal_nan=True)
+        return
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()

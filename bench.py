@@ -216,6 +216,63 @@ def abi_end_to_end(lib, shape, psf_edge, n_views, iterations, device, pad_mode):
             "result_finite_and_changed": ok}
 
 
+def exact_halo_mode(lib, devices, shape, psf_edge, n_views, steps, warmup, check_device):
+    """The same problem as ONE volume cut into dim0 slabs over `devices` of THIS process (mvn_group_*: what
+    MVN_DEVICES runs inside inplace_gpu_deconvolve; libmultiviewnative_amd/csrc/mvn_multi.cpp): the reference's
+    sequential sweep, halos pulled from the neighbours before every dim0 leg.  Stacks resident; timed like the
+    headline (wall time of `steps` sweeps between two all-slab syncs).  Parity: the result must equal the
+    one-device engine's sequential sweep BIT FOR BIT (that sweep is what the parity tests hold against the oracle)."""
+    import numpy as np
+    from libmultiviewnative_amd.abi import WorkspaceHolder
+    views, k1s, k2s = [], [], []
+    for v in range(n_views):
+        view, k1, k2 = make_view(shape, v, psf_edge)
+        views.append(view)
+        k1s.append(k1)
+        k2s.append(k2)
+    w = np.full(shape, 1.0 / n_views, np.float32)
+    h = WorkspaceHolder(views, k1s, k2s, [w] * n_views, LAMBDA, MIN_VALUE, steps)
+    psi0 = np.full(shape, np.float32(start_value()), np.float32)
+    g = lib.group(devices, shape, max(1, min(psf_edge, shape[0]) // 2), n_views)
+    try:
+        g.load(psi0, h)
+        if warmup > 0:
+            g.iterate(warmup, LAMBDA, MIN_VALUE)
+        ms = g.iterate(steps, LAMBDA, MIN_VALUE)
+        got = g.get_psi()
+    finally:
+        g.close()
+    out = {"update_mode": "sequential (reference order, Gauss-Seidel) on dim0 slabs: halo exchange of 2 x %d planes per "
+                          "convolution and neighbour pair, peer copies under the interior planes' dim0 leg"
+                          % max(1, min(psf_edge, shape[0]) // 2),
+           "devices": list(devices), "value": round(steps / (ms * 1e-3), 4), "unit": "iterations/s",
+           "ms_per_step": round(ms / steps, 4), "steps": steps, "warmup": warmup,
+           "psi_finite_positive": bool(np.isfinite(got).all() and (got > 0).all())}
+    # (the slabs keep the Nyquist bins packed in the DC column; the one-device engine does so by itself only up to
+    # 256 MB per volume - asked to, it runs the same arithmetic and the comparison is bit for bit)
+    packed_before = os.environ.get("MVN_NYQ_PACKED")
+    os.environ["MVN_NYQ_PACKED"] = "1"
+    try:
+        e = lib.engine(shape, n_views, device=check_device)
+    finally:
+        if packed_before is None:
+            os.environ.pop("MVN_NYQ_PACKED", None)
+        else:
+            os.environ["MVN_NYQ_PACKED"] = packed_before
+    try:
+        for v in range(n_views):
+            e.set_view(v, views[v], w, k1s[v], k2s[v])
+        e.set_psi(psi0)
+        e.iterate(warmup + steps, LAMBDA, MIN_VALUE, sync=True)
+        one = e.get_psi()
+    finally:
+        e.close()
+    out["parity"] = {"case": "psi after %d sweeps vs the one-device engine's sequential sweep" % (warmup + steps),
+                     "bit_equal": bool(np.array_equal(got, one)),
+                     "max_rel": float(np.abs(got.astype(np.float64) - one).max() / np.abs(one).max())}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -475,8 +532,41 @@ def run_rank(args, world_env):
                     # padded extents (512 + 31 - 1 = 542 -> 560), what a Fiji block gets
                     out["abi_end_to_end"]["reference_gpu_policy"] = abi_end_to_end(
                         lib, shape, psf_edge, V, its, local_rank, "zero")
+                    # the same call cut into two dim0 slabs (MVN_DEVICES; both on this device: the rehearsal a
+                    # one-GPU box allows - on a node the entries name different GPUs)
+                    os.environ["MVN_DEVICES"] = "%d,%d" % (local_rank, local_rank)
+                    try:
+                        out["abi_end_to_end"]["cyclic_policy_MVN_DEVICES_two_slabs_one_gpu"] = abi_end_to_end(
+                            lib, shape, psf_edge, V, its, local_rank, "none")
+                    finally:
+                        os.environ.pop("MVN_DEVICES", None)
+            if world == 1 and not args.no_abi:
+                # ONE slab that is its own neighbour (cyclic self-exchange): what the slab mode costs on a device
+                # before any link is involved - own planes + 2 x h halo planes, the exchange, the split leg
+                out["exact_halo_mode"] = exact_halo_mode(lib, [local_rank], shape, psf_edge, V, args.steps,
+                                                         args.warmup, local_rank)
+                # two slabs sharing the one device: a rehearsal of the concurrency (threads, events, copies under
+                # compute) - its TIME is that of two full-device launch chains competing for one GPU
+                out["exact_halo_mode"]["two_slabs_one_gpu_rehearsal"] = exact_halo_mode(
+                    lib, [local_rank, local_rank], shape, psf_edge, V, args.steps, args.warmup, local_rank)
         except Exception as e:  # the headline number must survive a failing side measurement
             out["side_measurement_error"] = "%s: %s" % (type(e).__name__, e)
+    if use_dist and world > 1 and not args.no_side and args.all_ranks_on_device < 0:
+        # The N > 1 lines' `value` is the north-star mode (views sharded, one all-reduce per iteration: Jacobi).
+        # The mode that keeps the REFERENCE's update order on N GPUs - dim0 slabs with a halo exchange, driven from
+        # ONE process (rank 0) - rides along.  The other ranks wait on the HOST (a key in the rendezvous store, not
+        # a collective: a device-side barrier would spin on the very GPUs being measured).
+        import datetime
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            try:
+                out["exact_halo_mode"] = exact_halo_mode(lib, list(range(world)), shape, psf_edge, V, args.steps,
+                                                         args.warmup, local_rank)
+            except Exception as e:  # the headline number must survive
+                out["exact_halo_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            store.set("mvn_exact_halo_done", "1")
+        else:
+            store.wait(["mvn_exact_halo_done"], datetime.timedelta(minutes=30))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

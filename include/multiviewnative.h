@@ -70,7 +70,12 @@ typedef struct workspace workspace;
 
 /* inc/multiviewnative.h:66-67 (impl. src/multiviewnative.cu:89-142): multi-view
  * Richardson-Lucy on the GPU.  psi: in/out, prod(data_[0].image_dims_) floats, host memory.
- * device < 0 selects a device automatically. */
+ * device < 0 selects a device automatically.
+ * Several GPUs (the reference drives one): with the environment variable MVN_DEVICES=0,1,..  (read per call) the
+ * call cuts the padded volume into slabs of dim0 planes, one per listed device, and sweeps them in the same
+ * view-after-view order with a halo exchange per convolution - same result as on one device, `device` is then
+ * ignored.  A call that cannot be cut that way (a PSF deeper than 33 planes, fewer planes per slab than half the
+ * deepest PSF, an odd last extent) runs on one device as usual.  See INTEGRATION.md section 4. */
 MVN_API void inplace_gpu_deconvolve(imageType* psi, struct workspace input, int device);
 
 /* inc/multiviewnative.h:59-61 (impl. src/multiviewnative.cu:58-75): in-place cyclic

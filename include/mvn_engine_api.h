@@ -55,6 +55,9 @@ MVN_API int mvn_psf_cache_counters(long out[2]);
 /* passes launched through the long-line (16-column, split-window) kernels since process start
  * (test / diagnostics; MVN_NO_SPLIT=1 keeps the 8-column kernels) */
 MVN_API long mvn_split_launch_count(void);
+/* inplace_gpu_deconvolve calls that ran as dim0 slabs on the devices of MVN_DEVICES (multiviewnative.h) since
+ * process start - a call that could not be cut that way ran on one device and is not counted */
+MVN_API long mvn_multi_device_calls(void);
 
 /* ---- plan_store (inc/plan_store.cuh: get()/add/has_key/empty/size/clear) ---------------- */
 MVN_API int mvn_plan_store_add(int device, const int dims[3]);
@@ -140,6 +143,16 @@ MVN_API int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void* user, void*
                                      void* user, int drain);
 MVN_API int mvn_engine_copy_planes(mvn_engine* e, void* spectrum, int plane0, int nplanes, void* buffer,
                                    int to_buffer);
+/* After mvn_engine_set_halo_hook: the first and last `planes` planes of the engine's volume are halo planes that no
+ * pass needs to compute - the last-axis and dim1 passes and the dim0 leg then run on the own planes only (a slab of
+ * 64 + 2 x 15 planes does the work of 64, not of 94).  split != 0: the leg runs in two parts - first the own planes
+ * that do not depend on the halos - and fn is called once more in between, with conv + 4: the halo planes have to be
+ * in place (in stream order) only when THAT call returns, so an exchange started at the first call on another
+ * stream runs beside the first part (mvn_multi.cpp does that; sharded.py passes 0). */
+MVN_API int mvn_engine_set_halo_planes(mvn_engine* e, int planes, int split);
+/* 1 / 0: would this engine hold a kernel of these extents in the direct dim0 form (which halo mode needs)?
+ * Lets a driver refuse a PSF when it is handed over instead of failing inside the first sweep. */
+MVN_API int mvn_engine_would_be_direct(mvn_engine* e, const int kdims[3]);
 /* Non-finite values in halo mode.  An FFT-based convolution turns ONE Inf / NaN voxel of its input into a volume of
  * NaN (inc/cpu_convolve.h:256-268), which the update then clamps to minValue everywhere (inc/cpu_kernels.h:40-47,
  * 76-83).  The direct dim0 leg reproduces that through a 4-byte device word per engine, the "poison word": a leg
@@ -171,6 +184,24 @@ MVN_API int mvn_kernel_kind_count(void);
 MVN_API const char* mvn_kernel_kind_name(int kind);
 /* algorithmic bytes B = 4*d0*d1*2(d2/2+1) of the engine's shape */
 MVN_API size_t mvn_engine_B(mvn_engine* e);
+
+/* ---- one volume on several devices of ONE process (what MVN_DEVICES runs inside inplace_gpu_deconvolve) ------
+ * The volume is cut into slabs of dim0 planes, one per entry of `devices` (an entry may repeat: two slabs on one
+ * device), each an ordinary resident engine on its planes plus `halo_planes` = (deepest PSF) / 2 halo planes either
+ * side, each driven by its own host thread; before every dim0 leg a slab pulls its neighbours' boundary planes with
+ * peer copies (cyclically: the reference's convolution is cyclic), under the part of the leg that does not need them.
+ * The sweep is the reference's view-after-view order (src/multiviewnative.cpp:194-227): results equal the
+ * one-device engine's bit for bit.  Needs PSFs of at most 33 planes (direct dim0 leg), an even last extent, at least
+ * halo_planes planes per slab, at most 8 slabs.  No communication library: events and hipMemcpyPeerAsync.
+ *   mvn_group_create -> mvn_group_load (psi and the workspace's stacks, extents == dims, uploaded slab by slab)
+ *   -> mvn_group_iterate (blocking; *ms = wall time of the sweeps, stacks resident) -> mvn_group_get_psi */
+typedef struct mvn_group mvn_group; /* opaque */
+MVN_API int mvn_group_create(const int* devices, int ndevices, const int dims[3], int halo_planes, int num_views,
+                             mvn_group** out);
+MVN_API int mvn_group_destroy(mvn_group* g);
+MVN_API int mvn_group_load(mvn_group* g, const float* psi, struct workspace input);
+MVN_API int mvn_group_iterate(mvn_group* g, int iterations, double lambda, float min_value, float* ms);
+MVN_API int mvn_group_get_psi(mvn_group* g, float* psi);
 
 /* ---- slab-decomposed engine: the SEQUENTIAL sweep on several GPUs ------
  * Rank `rank` of `nranks` keeps planes [rank*d0/nranks, (rank+1)*d0/nranks) of psi, of every

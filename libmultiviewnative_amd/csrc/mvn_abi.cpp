@@ -19,6 +19,7 @@
 #include "../../include/mvn_engine_api.h"
 #include "mvn_engine.hpp"
 #include "mvn_fixed_geom.hpp"
+#include "mvn_multi.hpp"
 
 using namespace mvn;
 
@@ -28,6 +29,10 @@ struct mvn_engine {
 
 struct mvn_slab {
   std::unique_ptr<SlabEngine> impl;
+};
+
+struct mvn_group {
+  std::unique_ptr<HaloGroup> impl;
 };
 
 static thread_local std::string g_last_error;
@@ -290,6 +295,75 @@ static void check_workspace(const imageType* psi, const workspace& input) {
   }
 }
 
+// ---- MVN_DEVICES: one call, several devices ---------------------------------------------------
+// MVN_DEVICES=0,1,2,3 makes inplace_gpu_deconvolve cut the (padded) volume into slabs of
+// dim0 planes, one per listed device, and sweep them in the reference's view order with a halo exchange per
+// convolution (mvn_multi.hpp) - the `device` argument is then ignored.  The call falls back to ONE device (its
+// usual path) when the volume cannot be cut that way: a PSF deeper than 33 planes (no direct dim0 leg), fewer
+// planes per slab than halo planes, an odd last extent, a slab that would hold padding only.  One group of slab
+// engines is kept between calls like the single-device engine (mvn_release_cached_engines frees it).
+static std::unique_ptr<HaloGroup>& multi_cache() {
+  static std::unique_ptr<HaloGroup>* g = new std::unique_ptr<HaloGroup>();
+  return *g;
+}
+
+static std::atomic<long> g_multi_calls{0};
+
+static bool multi_device_call(imageType* psi, const workspace& input, const shape_t& dims, const shape_t& ext,
+                              const int off[3], int pad_mode, const std::vector<int>& devs) {
+  const int V = input.num_views_;
+  int h = 1;
+  for (int v = 0; v < V; ++v)
+    h = std::max(h, std::max(input.data_[v].kernel1_dims_[0], input.data_[v].kernel2_dims_[0]) / 2);
+  const int P = (int)devs.size();
+  auto refuse = [&](const char* why) {
+    if (trace_on()) std::printf("[lmvn::trace] MVN_DEVICES: %s - one device\n", why);
+    return false;
+  };
+  if (!HaloGroup::feasible(P, ext, h)) return refuse("the volume cannot be cut into that many slabs");
+  for (int r = 0; r < P; ++r) {  // every slab holds planes of the stacks, not padding only
+    const int z0 = (int)((long)r * ext[0] / P), z1 = (int)((long)(r + 1) * ext[0] / P);
+    if (std::min(z1, off[0] + dims[0]) <= std::max(z0, off[0])) return refuse("a slab would hold padding only");
+  }
+  std::vector<int> distinct(devs);
+  std::sort(distinct.begin(), distinct.end());
+  distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+  std::vector<std::unique_lock<std::mutex>> locks;  // ascending order: no two calls can wait for each other
+  for (int d : distinct) locks.emplace_back(device_mutex(d));
+  std::unique_ptr<HaloGroup> group;
+  {
+    std::lock_guard<std::mutex> lk(engine_cache_mutex());
+    group = std::move(multi_cache());
+  }
+  if (group && !(engine_cache_enabled() && group->matches(devs, ext, h, V))) group.reset();
+  if (!group) {
+    for (int d : distinct) {  // the single-device engines cached on these devices would compete for the memory
+      be::set_device(d);
+      pop_cached_engine(d).reset();
+    }
+    try {
+      group.reset(new HaloGroup(devs, ext, h, V));
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "[libmultiviewnative] MVN_DEVICES ignored for this call: %s\n", e.what());
+      return false;
+    }
+  }
+  if (!group->all_direct(input)) {
+    group.reset();
+    return refuse("a PSF is not held in the direct dim0 form");
+  }
+  if (trace_on())
+    std::printf("[lmvn::trace] MVN_DEVICES: %d slabs of %d x %d x %d, %d halo planes either side\n", P, ext[0], ext[1],
+                ext[2], h);
+  group->run(psi, input, dims, off, pad_mode == MVN_PAD_ZERO);  // (on failure the group is dropped)
+  ++g_multi_calls;
+  if (engine_cache_enabled()) {
+    std::lock_guard<std::mutex> lk(engine_cache_mutex());
+    multi_cache() = std::move(group);
+  }
+  return true;
+}
+
 static void deconvolve_call(imageType* psi, const workspace& input, int device, int lane, int pad_mode) {
   {
     check_workspace(psi, input);
@@ -328,6 +402,10 @@ static void deconvolve_call(imageType* psi, const workspace& input, int device, 
         }
         ext[d] = good_extent(ext[d], d == 2);
       }
+    }
+    if (lane == 0) {  // (the second lane belongs to the block pipeline of mvn_deconvolve_submit)
+      const std::vector<int> devs = multi_devices_from_env();
+      if (!devs.empty() && multi_device_call(psi, input, dims, ext, off, pad_mode, devs)) return;
     }
     const int dev = pick_device(device);
     const int key = dev + lane * kLaneStride;
@@ -818,10 +896,77 @@ int mvn_release_cached_engines(void) {
       std::lock_guard<std::mutex> lk(device_mutex(d));  // not while a call on that device runs
       pop_cached_engine(d).reset();
     }
+    std::unique_ptr<HaloGroup> group;
+    {
+      std::lock_guard<std::mutex> lk(engine_cache_mutex());
+      group = std::move(multi_cache());
+    }
+    if (group) {
+      std::vector<int> distinct(group->devices());
+      std::sort(distinct.begin(), distinct.end());
+      distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+      std::vector<std::unique_lock<std::mutex>> locks;
+      for (int d : distinct) locks.emplace_back(device_mutex(d));
+      group.reset();
+    }
   });
 }
 
 long mvn_split_launch_count(void) { return be::split_launch_count(); }
+long mvn_multi_device_calls(void) { return g_multi_calls.load(); }
+
+// ---- resident group of slab engines (what MVN_DEVICES runs inside inplace_gpu_deconvolve) -----
+int mvn_group_create(const int* devices, int ndevices, const int dims[3], int halo_planes, int num_views,
+                     mvn_group** out) {
+  return guarded("mvn_group_create", [&] {
+    if (!devices || !dims || !out) throw std::invalid_argument("null argument");
+    *out = nullptr;
+    std::vector<int> devs(devices, devices + (ndevices > 0 ? ndevices : 0));
+    for (int d : devs)
+      if (d < 0 || d >= be::device_count()) throw std::invalid_argument("no such device");
+    std::unique_ptr<mvn_group> g(new mvn_group());
+    g->impl.reset(new HaloGroup(devs, to_shape(dims), halo_planes < 1 ? 1 : halo_planes, num_views));
+    *out = g.release();
+  });
+}
+
+int mvn_group_destroy(mvn_group* g) {
+  return guarded("mvn_group_destroy", [&] { delete g; });
+}
+
+#define MVN_GROUP_CALL(where, ...)                                               \
+  return guarded(where, [&] {                                                    \
+    if (!g || !g->impl) throw std::invalid_argument("null group");               \
+    HaloGroup& G = *g->impl;                                                     \
+    __VA_ARGS__;                                                                 \
+  })
+
+int mvn_group_load(mvn_group* g, const float* psi, struct workspace input) {
+  MVN_GROUP_CALL("mvn_group_load", {
+    check_workspace(psi, input);
+    if (input.num_views_ != G.num_views()) throw std::invalid_argument("view count of the group");
+    for (int v = 0; v < input.num_views_; ++v)
+      if (to_shape(input.data_[v].image_dims_) != G.extents())
+        throw std::invalid_argument("stacks must have the extents the group was created for");
+    if (!G.all_direct(input)) throw std::invalid_argument("every PSF must be held in the direct dim0 form (<= 33 planes)");
+    const int off[3] = {0, 0, 0};
+    G.load(psi, input, G.extents(), off, false);
+  });
+}
+
+int mvn_group_iterate(mvn_group* g, int iterations, double lambda, float min_value, float* ms) {
+  MVN_GROUP_CALL("mvn_group_iterate", {
+    const double t = G.iterate(iterations, lambda, min_value);
+    if (ms) *ms = (float)t;
+  });
+}
+
+int mvn_group_get_psi(mvn_group* g, float* psi) {
+  MVN_GROUP_CALL("mvn_group_get_psi", {
+    if (!psi) throw std::invalid_argument("null psi");
+    G.fetch(psi);
+  });
+}
 
 int mvn_psf_cache_counters(long out[2]) {
   return guarded("mvn_psf_cache_counters", [&] {
@@ -1224,6 +1369,20 @@ int mvn_engine_bind_delta(mvn_engine* e, void* dev_ptr) {
 
 int mvn_engine_set_halo_hook(mvn_engine* e, void (*fn)(void*, void*, int, int), void* user, int drain) {
   MVN_ENGINE_CALL("mvn_engine_set_halo_hook", E.set_halo_hook(fn, user, (drain & 1) != 0, (drain & 2) != 0));
+}
+
+int mvn_engine_would_be_direct(mvn_engine* e, const int kdims[3]) {
+  int yes = 0;
+  const int rc = guarded("mvn_engine_would_be_direct", [&] {
+    if (!e || !e->impl || !kdims) throw std::invalid_argument("null argument");
+    be::set_device(e->impl->device());
+    yes = e->impl->would_be_direct(kdims) ? 1 : 0;
+  });
+  return rc < 0 ? rc : yes;
+}
+
+int mvn_engine_set_halo_planes(mvn_engine* e, int planes, int split) {
+  MVN_ENGINE_CALL("mvn_engine_set_halo_planes", E.set_halo_planes(planes, split != 0));
 }
 
 int mvn_engine_poison_ptr(mvn_engine* e, void** dev_ptr) {

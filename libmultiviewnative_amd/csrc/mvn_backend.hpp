@@ -41,6 +41,11 @@ void d2h_2d(void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, 
 void d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
             stream_t s);
 void dzero(void* d, size_t bytes, stream_t s);
+// several devices in one process (slabs of one volume, mvn_multi.cpp): let kernels and copies running on `dev`
+// reach memory of `peer` (once per pair; a no-op for dev == peer), and a device-to-device copy between two
+// devices' memories enqueued on a stream of either
+void enable_peer_access(int dev, int peer);
+void copy_peer(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, stream_t s);
 
 stream_t stream_create();
 // a stream of the device's highest priority: it gets hardware queues of its own, so that host->device
@@ -83,8 +88,10 @@ void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int nthreads, size_t 
                          stream_t s);
 // launches that went through the long-line (split-window, 16-column) kernels since process start
 long split_launch_count();
+// `rider` (plain fixed-length passes only): a second pass of the same mode with tiles of ONE line (T = 1, run-time
+// radix body) - the lines of the Nyquist plane, taken by rider->tiles_per_outer further workgroups of the same launch
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
-                    size_t lds_bytes, stream_t s);
+                    size_t lds_bytes, stream_t s, const StridedParams* rider = nullptr, size_t rider_lds = 0);
 
 // the dim0 leg of a convolution as a direct cyclic convolution with the PSF's few planes
 // (mvn_dim0_direct.hpp); p.k must satisfy mvn_dim0_direct_possible(p.k, p.d0)

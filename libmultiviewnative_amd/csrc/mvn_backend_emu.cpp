@@ -117,6 +117,10 @@ void d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t wid
     std::memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
 }
 void dzero(void* d, size_t bytes, stream_t) { std::memset(d, 0, bytes); }
+void enable_peer_access(int dev, int peer) {
+  if (dev < 0 || dev >= device_count() || peer < 0 || peer >= device_count()) throw std::runtime_error("emu: invalid peer");
+}
+void copy_peer(void* dst, int, const void* src, int, size_t bytes, stream_t) { std::memmove(dst, src, bytes); }
 
 stream_t stream_create() { return (stream_t)1; }
 stream_t stream_create_upload() { return (stream_t)1; }
@@ -391,9 +395,26 @@ void launch_rows_c2r(const RowsParams& p0, bool even, long ntiles, int, size_t l
 }
 
 void launch_strided(int mode, const StridedParams& p, long nblocks, int, size_t lds_bytes,
-                    stream_t) {
+                    stream_t, const StridedParams* rider, size_t rider_lds) {
+  if (rider && (!p.fixed || mode == MVN_ST_FWD_MUL_INV || rider->T != 1 || rider->fixed || rider_lds > 160 * 1024))
+    throw std::invalid_argument("mvn: Nyquist lines ride only in the plain fixed-length strided passes, one per workgroup");
   if (p.fixed) {
     if (!emu_strided_fixed_dispatch(mode, p, nblocks)) throw std::invalid_argument("mvn: no fixed kernel");
+    if (rider) {  // the workgroups behind the walkers: one line each
+      const long lines = rider->tiles_per_outer;
+#pragma omp parallel
+      {
+        std::vector<char> lds(rider_lds + 64);
+#pragma omp for schedule(static)
+        for (long b = 0; b < lines; ++b) {
+          cfloat* l = (cfloat*)lds.data();
+          if (mode == MVN_ST_FWD)
+            strided_body<MVN_ST_FWD, 1, true>(*rider, b, 0, 1, l);
+          else
+            strided_body<MVN_ST_INV, 1, true>(*rider, b, 0, 1, l);
+        }
+      }
+    }
     return;
   }
 #pragma omp parallel

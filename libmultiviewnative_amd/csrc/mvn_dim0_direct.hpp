@@ -70,9 +70,18 @@ struct Dim0DirectParams {
   unsigned poison_epoch;
   int n_peers;
   unsigned* const* poison_peers;
+  // zcount > 0: only the output planes [zbeg, zbeg + zcount) are produced (a slab whose first and last planes are
+  // halo planes computes its own planes only - and those that do not depend on the halos before they arrive);
+  // the inputs are read cyclically over all d0 planes as ever.  0: all d0 planes.
+  int zbeg, zcount;
 };
 
+#ifndef MVN_D0_PF
 #define MVN_D0_PF 4         // planes requested ahead
+#endif
+#ifndef MVN_D0_CHAINS
+#define MVN_D0_CHAINS 2     // independent pairs of multiply-add chains per output (1 or 2)
+#endif
 #define MVN_D0_MAX_TAPS 33  // largest instantiated K
 
 // K the direct kernel is instantiated for: k itself if odd, else k + 1 (one zero tap)
@@ -91,6 +100,23 @@ MVN_HD cfloat mvn_cmac(cfloat acc, cfloat a, cfloat w) {
   return r;
 #else
   return cmake(acc.x + a.x * w.x - a.y * w.y, acc.y + a.x * w.y + a.y * w.x);
+#endif
+}
+
+// The K complex multiply-adds of an output as TWO independent chains of packed fused multiply-adds,
+//     s1 += (a.x w.x, a.x w.y),   s2 += (a.y w.x, a.y w.y),   out = (s1.x - s2.y, s1.y + s2.x),
+// each with one half of the input broadcast as its first operand.  Same instruction count as the single chain of
+// round 3 (acc += a.x w, then acc += i a.y w), but consecutive instructions never depend on each other: behind an
+// inline instruction the compiler places a wait state in front of every instruction that reads its result, 2 K of
+// them per output in the single chain.  (Left to the compiler's own packed multiply-adds the unrolled walk is
+// re-scheduled across steps and needs 255 registers, or spills when bounded: the inline forms also pin the order.)
+MVN_HD void mvn_cmac2(cfloat& s1, cfloat& s2, cfloat a, cfloat w) {
+#if defined(MVN_PACKED)
+  MVN_PK3(s1, "v_pk_fma_f32", a, w, s1, "op_sel_hi:[0,1,1]");
+  MVN_PK3(s2, "v_pk_fma_f32", a, w, s2, "op_sel:[1,0,0] op_sel_hi:[1,1,1]");
+#else
+  s1 = cmake(s1.x + a.x * w.x, s1.y + a.x * w.y);
+  s2 = cmake(s2.x + a.y * w.x, s2.y + a.y * w.y);
 #endif
 }
 
@@ -136,11 +162,16 @@ MVN_HD void mvn_dim0_dc_load(const Dim0DirectParams& P, int pair, cfloat* lds, i
   cfloat* U = lds + 2 * (long)P.d0;
   cfloat* V = U + P.k;
   cfloat bad = cmake(0.f, 0.f);
+  // tracked like the other work items' planes: in[z + h] for every output plane z of the launch (a ranged launch
+  // may run before the halo planes of the input have arrived: what they still hold must not be looked at)
+  const int zlo = P.zcount > 0 ? P.zbeg : 0, nplanes = P.zcount > 0 ? P.zcount : P.d0;
   for (int z = tid; z < P.d0; z += nthreads) {
     const cfloat va = P.in[(long)z * P.plane + ra], vb = P.in[(long)z * P.plane + rb];
     a[z] = va;
     b[z] = vb;
-    bad = mvn_dim0_track(mvn_dim0_track(bad, va), vb);
+    int rel = z - zlo - P.h;
+    rel = rel < 0 ? rel + P.d0 : rel;
+    if (rel < nplanes) bad = mvn_dim0_track(mvn_dim0_track(bad, va), vb);
   }
   if (bad.x != 0.f || bad.y != 0.f) mvn_dim0_report(P);
   for (int j = tid; j < P.k; j += nthreads) {
@@ -159,7 +190,8 @@ MVN_HD void mvn_dim0_dc_compute(const Dim0DirectParams& P, int pair, const cfloa
   const cfloat* b = lds + P.d0;
   const cfloat* U = lds + 2 * (long)P.d0;
   const cfloat* V = U + P.k;
-  for (int z = tid; z < P.d0; z += nthreads) {
+  const int zlo = P.zcount > 0 ? P.zbeg : 0, zhi = P.zcount > 0 ? P.zbeg + P.zcount : P.d0;
+  for (int z = zlo + tid; z < zhi; z += nthreads) {
     cfloat s1 = cmake(0.f, 0.f), s2 = cmake(0.f, 0.f);
     int zi = z + P.h;
     zi = zi >= P.d0 ? zi - P.d0 : zi;
@@ -188,12 +220,13 @@ struct Dim0Blocks {
 };
 MVN_HD Dim0Blocks mvn_dim0_blocks(const Dim0DirectParams& P) {
   Dim0Blocks B;
-  B.seg1 = P.seg1 > 0 ? P.seg1 : P.d0;
-  B.seg2 = P.seg2 > 0 ? P.seg2 : P.d0;
+  const int planes = P.zcount > 0 ? P.zcount : P.d0;  // output planes of the launch
+  B.seg1 = P.seg1 > 0 ? P.seg1 : planes;
+  B.seg2 = P.seg2 > 0 ? P.seg2 : planes;
   B.nb1 = (P.plane + MVN_D0_WG - 1) / MVN_D0_WG;
   B.nb2 = (P.packed || P.plane2 <= 0) ? 0 : (P.plane2 + MVN_D0_WG - 1) / MVN_D0_WG;
-  B.main_blocks = B.nb1 * ((P.d0 + B.seg1 - 1) / B.seg1);
-  B.blocks = B.main_blocks + B.nb2 * ((P.d0 + B.seg2 - 1) / B.seg2);  // (+ mvn_dim0_pairs(d1) workgroups when packed)
+  B.main_blocks = B.nb1 * ((planes + B.seg1 - 1) / B.seg1);
+  B.blocks = B.main_blocks + B.nb2 * ((planes + B.seg2 - 1) / B.seg2);  // (+ mvn_dim0_pairs(d1) workgroups when packed)
   return B;
 }
 // workgroup `block`, lane `tid`: the arrays (Q), the bin b the lane owns there and the output planes
@@ -202,13 +235,20 @@ MVN_HD bool mvn_dim0_job(const Dim0DirectParams& P, long block, int tid, Dim0Dir
                          int& nout) {
   const Dim0Blocks B = mvn_dim0_blocks(P);
   Q = P;
+  const bool ranged = P.zcount > 0;
+  const int zlo = ranged ? P.zbeg : 0, zhi = ranged ? P.zbeg + P.zcount : P.d0;
   if (block < B.main_blocks) {
     const long piece = block / B.nb1;
     b = (block - piece * B.nb1) * MVN_D0_WG + tid;
     // whole columns: workgroups start their cyclic walk at different planes (all of them on one plane at a time
     // keep the whole chip on 1 MB in and 1 MB out)
-    z0 = P.seg1 > 0 ? (int)(piece * B.seg1) : (P.stagger > 0 ? (int)((block * P.stagger) % P.d0) : 0);
-    nout = P.seg1 > 0 ? (P.d0 - z0 < B.seg1 ? P.d0 - z0 : B.seg1) : P.d0;
+    if (P.seg1 > 0 || ranged) {
+      z0 = zlo + (int)(piece * B.seg1);
+      nout = zhi - z0 < B.seg1 ? zhi - z0 : B.seg1;
+    } else {
+      z0 = P.stagger > 0 ? (int)((block * P.stagger) % P.d0) : 0;
+      nout = P.d0;
+    }
     if (b >= P.plane) return false;
     return !(P.packed && b % P.C == 0);  // the packed DC column belongs to the pair workgroups
   }
@@ -216,13 +256,13 @@ MVN_HD bool mvn_dim0_job(const Dim0DirectParams& P, long block, int tid, Dim0Dir
   const long block2 = block - B.main_blocks;
   const long piece = block2 / B.nb2;
   b = (block2 - piece * B.nb2) * MVN_D0_WG + tid;
-  z0 = (int)(piece * B.seg2);
-  nout = P.d0 - z0 < B.seg2 ? P.d0 - z0 : B.seg2;
+  z0 = zlo + (int)(piece * B.seg2);
+  nout = zhi - z0 < B.seg2 ? zhi - z0 : B.seg2;
   Q.in = P.in2;
   Q.out = P.out2;
   Q.taps = P.taps2;
   Q.plane = P.plane2;
-  return z0 < P.d0 && b < P.plane2;
+  return z0 < zhi && b < P.plane2;
 }
 // Piece length for the main columns of a (d0, plane) volume: as many pieces as bring a launch to `want` work
 // items, but none shorter than 2 K + 8 planes (every piece reads its K + 3 window planes again); 0 = whole
@@ -318,10 +358,28 @@ template <int K, int PF, int U>
 MVN_HD void mvn_dim0_step(Dim0Window<K, PF>& r, Dim0Walk& w, unsigned b, int nout, int nn) {
   constexpr int KW = K + PF;
   if (nn + U >= nout) return;  // nout outputs in all, the walk is cyclic
-  cfloat acc = cmake(0.f, 0.f);
+  cfloat s1 = cmake(0.f, 0.f), s2 = cmake(0.f, 0.f);
+#if defined(MVN_EXPERIMENTS) && defined(MVN_D0_EXP_TAPS)
+  // timing experiment (variant builds only, WRONG results): the walk with only the first few multiply-adds
 #pragma unroll
-  for (int j = 0; j < K; ++j) acc = mvn_cmac(acc, r.w[(j + PF - U + KW) % KW], r.tap[j]);
-  mvn_dim0_st(w.pout, b, w.bytes, acc);
+  for (int j = 0; j < (K < MVN_D0_EXP_TAPS ? K : MVN_D0_EXP_TAPS); ++j) mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
+#elif MVN_D0_CHAINS == 2
+  // even and odd taps in chains of their own: four instructions between a multiply-add and the next one of its
+  // chain - the compiler asks for two between inline instructions and fills what is missing with wait states
+  cfloat t1 = cmake(0.f, 0.f), t2 = cmake(0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j + 1 < K; j += 2) {
+    mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
+    mvn_cmac2(t1, t2, r.w[(j + 1 + PF - U + KW) % KW], r.tap[j + 1]);
+  }
+  if (K % 2) mvn_cmac2(s1, s2, r.w[(K - 1 + PF - U + KW) % KW], r.tap[K - 1]);
+  s1 = cadd(s1, t1);
+  s2 = cadd(s2, t2);
+#else
+#pragma unroll
+  for (int j = 0; j < K; ++j) mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
+#endif
+  mvn_dim0_st(w.pout, b, w.bytes, cadd_i<+1>(s1, s2));  // (s1.x - s2.y, s1.y + s2.x)
   // x_0 = in[z + h] runs over every plane of the column once: tracked HERE, where it has long arrived
   // (at its load the check would stall on the request that was just issued)
   r.bad = mvn_dim0_track(r.bad, r.w[(PF - U + KW) % KW]);

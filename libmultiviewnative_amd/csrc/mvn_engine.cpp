@@ -221,6 +221,7 @@ Plan3D::Plan3D(int dev, int d0, int d1, int d2)
   g_ax0f = pick_geom(ax0.host.nfft, ax0.host.generic, false, env_int("MVN_T_FUSED", 16));
   g_nyq1 = g_ax1;
   g_nyq0 = g_ax0;
+  g_nyq1_line = pick_geom(ax1.host.nfft, ax1.host.generic, false, 1);  // one line per workgroup (riders)
   // fixed-length fast path: full tiles, 16-byte aligned rows
   {
     int T = 0, threads = 0;
@@ -348,9 +349,18 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   be::launch_rows_c2r(p, L.even, ntiles, g_rows.threads, g_rows.lds_bytes, s);
 }
 
-void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, be::stream_t s,
-                          Profiler* prof) const {
+void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi_all, be::stream_t s,
+                          Profiler* prof, long row0, long nrows) const {
   if (!L.even) throw std::logic_error("mvn: rows_c2r_r2c needs an even last extent");
+  const long R = rows_in_range(*this, row0, nrows);
+  data += row0 * L.C;
+  if (nyq) nyq += row0;
+  EpilogueParams epi = epi_all;
+  const long eoff = row0 * L.RP;
+  if (epi.view) epi.view += eoff;
+  if (epi.psi) epi.psi += eoff;
+  if (epi.weights) epi.weights += eoff;
+  if (epi.delta) epi.delta += eoff;
   RowsParams p;
   std::memset(&p, 0, sizeof(p));
   p.ax = ax2.view;
@@ -359,7 +369,7 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, 
   p.h = L.h;
   p.C = L.C;
   p.RP = L.RP;
-  p.rows = (long)L.rows;
+  p.rows = R;
   p.in_cplx = data;
   p.in_nyq = nyq;
   p.out_cplx = data;
@@ -374,7 +384,7 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, 
   if (fx_rows) {
     p.fixed = 1;
     p.T = gx_rows.T;
-    be::launch_rows_c2r_r2c(p, (long)L.rows / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
+    be::launch_rows_c2r_r2c(p, R / p.T, gx_rows.threads, gx_rows.lds_bytes, s);
     return;
   }
   p.T = g_rows.T;
@@ -383,7 +393,7 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, 
   p.lds_tw = g_rows.lds_tw;
   p.hmul = mvn_fastdiv_mul((unsigned)L.h);
   p.Cmul = mvn_fastdiv_mul((unsigned)L.C);
-  const long ntiles = ((long)L.rows + p.T - 1) / p.T;
+  const long ntiles = (R + p.T - 1) / p.T;
   be::launch_rows_c2r_r2c(p, ntiles, g_rows.threads, g_rows.lds_bytes, s);
 }
 
@@ -438,21 +448,36 @@ void Plan3D::axis1(int mode, cfloat* data, cfloat* nyq, be::stream_t s, Profiler
   if (z0 < 0 || nz < 1 || z0 + nz > L.d0) throw std::out_of_range("mvn: plane range of a dim1 pass");
   data += (size_t)z0 * L.d1 * L.C;
   if (nyq) nyq += (size_t)z0 * L.d1;
+  const bool ride = nyq_rides() && L.even && nyq;
   {
     // main array [d0][d1][C]: lines along d1, tiles of neighbouring bins
     const PassGeom& g = fx_ax1 ? gx_ax1 : g_ax1;
     StridedParams p = make_strided(ax1, g, data, nullptr, (long)L.d1 * L.C, L.C, 1, L.C);
     p.fixed = fx_ax1 ? 1 : 0;
     ProfScope ps(prof, mode == MVN_ST_FWD ? KK_AXIS1_FWD : KK_AXIS1_INV, s);
-    be::launch_strided(mode, p, (long)nz * p.tiles_per_outer, g.threads, g.lds_bytes, s);
+    if (ride) {
+      // the Nyquist plane [d0][d1] rides in the same launch: its nz lines (contiguous along d1), one per workgroup
+      StridedParams r = make_strided(ax1, g_nyq1_line, nyq, nullptr, 0, 1, L.d1, nz);
+      r.is_nyq = 1;
+      be::launch_strided(mode, p, (long)nz * p.tiles_per_outer, g.threads, g.lds_bytes, s, &r, g_nyq1_line.lds_bytes);
+    } else {
+      be::launch_strided(mode, p, (long)nz * p.tiles_per_outer, g.threads, g.lds_bytes, s);
+    }
   }
-  if (L.even && nyq) {  // (no plane: the Nyquist bins are packed into column 0 of the main array)
+  if (L.even && nyq && !ride) {  // (no plane: the Nyquist bins are packed into column 0 of the main array)
     // Nyquist plane [d0][d1]: lines along d1 are contiguous, neighbouring lines d1 apart
     StridedParams p = make_strided(ax1, g_nyq1, nyq, nullptr, 0, 1, L.d1, nz);
     p.is_nyq = 1;
     ProfScope ps(s_nyq == s ? prof : nullptr, KK_NYQ, s_nyq);
     be::launch_strided(mode, p, p.tiles_per_outer, g_nyq1.threads, g_nyq1.lds_bytes, s_nyq);
   }
+}
+
+// The Nyquist plane's dim1 transforms ride in the main array's launches where those are the fixed-length walking
+// kernels (MVN_NYQ_RIDE=0: launches of their own, on the stream the caller names, as in rounds 1 - 3)
+bool Plan3D::nyq_rides() const {
+  static const bool off = env_int("MVN_NYQ_RIDE", 1) == 0;  // A/B knob
+  return fx_ax1 && !off;
 }
 
 bool Plan3D::tiles_spectra() const {
@@ -517,7 +542,8 @@ void Plan3D::middle_passes(cfloat* work, cfloat* work_nyq, const cfloat* spec,
                            const cfloat* spec_nyq, be::stream_t s, Profiler* prof,
                            SideStream* side, bool spec_tiled) const {
   be::stream_t sn = s;
-  if (side && side->s && L.even) {
+  // (where the plane's dim1 transforms ride in the main launches, its dim0 launch runs in line between them)
+  if (side && side->s && L.even && !nyq_rides()) {
     side->fork_from(s);  // the plane was written by the last-axis pass just enqueued on s
     sn = side->s;
   }
@@ -874,8 +900,9 @@ void Engine::ensure_work2() {
 // DC + i Nyquist column separated inside it.  Split layout: sn == stream_: main array and Nyquist plane in ONE
 // launch on the engine's stream; otherwise the Nyquist plane as a launch of its own on sn
 void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out,
-                       cfloat* out_nyq, Profiler* prof, be::stream_t sn) {
+                       cfloat* out_nyq, Profiler* prof, be::stream_t sn, int zbeg, int zcount, bool first) {
   const Layout& L = plan_->L;
+  if (zcount < 0 || zbeg < 0 || zbeg + zcount > L.d0) throw std::out_of_range("mvn: plane range of a dim0 leg");
   Dim0DirectParams p;
   std::memset(&p, 0, sizeof(p));
   p.in = in;
@@ -887,11 +914,14 @@ void Engine::dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat*
   p.h = s.tap_k[i] / 2;
   p.plane = (long)L.d1 * L.C;
   p.stagger = d0_stagger_;
-  p.seg1 = mvn_dim0_piece_len(p.k, L.d0, p.plane, direct_min_plane_);
+  p.zbeg = zbeg;
+  p.zcount = zcount;
+  p.seg1 = mvn_dim0_piece_len(p.k, zcount > 0 ? zcount : L.d0, p.plane, direct_min_plane_);
   p.C = L.C;
   p.d1 = L.d1;
-  // non-finite inputs are reported under this leg's epoch (never 0, never a value the word may still hold)
-  if (++epoch_ == 0x7fffffffu) {
+  // non-finite inputs are reported under this leg's epoch (never 0, never a value the word may still hold); the
+  // launches of one leg (a slab's interior planes, then those next to its halos) share it
+  if (first && ++epoch_ == 0x7fffffffu) {
     be::dzero(poison_, sizeof(unsigned), stream_);
     epoch_ = 1;
   }
@@ -1001,19 +1031,46 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
   if (packed_) {
     // no Nyquist plane, no second stream: three launches on stream_
     if (!s.tap_k[i]) throw std::logic_error("mvn: packed Nyquist layout with a kernel that is not in the direct form");
-    P.axis1(MVN_ST_FWD, (cfloat*)work_, nullptr, stream_, prof, stream_);
+    // Halo mode: the first and last H planes of the volume are the neighbours'.  No pass computes them - the
+    // last-axis and dim1 passes run on the own planes [H, d0 - H) only, the leg produces only those - and the leg
+    // runs in two parts: the planes that do not depend on the halos first, so that the exchange (the hook's
+    // business) can go on beside them, then - behind the hook's second call - the H planes next to either halo.
+    const int H = halo_ranged() ? halo_planes_ : 0;
+    const int own = P.L.d0 - 2 * H;
+    const int view = (int)(&s - views_.data());
+    P.axis1(MVN_ST_FWD, (cfloat*)work_, nullptr, stream_, prof, stream_, H, own);
     if (halo_fn_) {  // the neighbours' planes arrive in the halo planes of the leg's input
       if (halo_drain_) be::stream_sync(stream_);
-      halo_fn_(halo_user_, work_, (int)(&s - views_.data()), i);
+      halo_fn_(halo_user_, work_, view, i);
     }
     ensure_work2();
-    dim0_conv(s, i, (const cfloat*)work_, nullptr, (cfloat*)work2_, nullptr, prof, stream_);
+    const cfloat* in = (const cfloat*)work_;
+    cfloat* out = (cfloat*)work2_;
+    if (H == 0) {
+      if (halo_fn_ && halo_split_) {  // (no ranges, e.g. rows that do not end on tile boundaries: one part)
+        if (halo_drain_) be::stream_sync(stream_);
+        halo_fn_(halo_user_, work_, view, i + 4);
+      }
+      dim0_conv(s, i, in, nullptr, out, nullptr, prof, stream_);
+    } else if (halo_split_ && own > 2 * H) {
+      dim0_conv(s, i, in, nullptr, out, nullptr, prof, stream_, 2 * H, own - 2 * H, true);
+      if (halo_drain_) be::stream_sync(stream_);
+      halo_fn_(halo_user_, work_, view, i + 4);  // the halo planes must be in place behind this call
+      dim0_conv(s, i, in, nullptr, out, nullptr, nullptr, stream_, H, H, false);
+      dim0_conv(s, i, in, nullptr, out, nullptr, nullptr, stream_, own, H, false);
+    } else {
+      if (halo_split_) {
+        if (halo_drain_) be::stream_sync(stream_);
+        halo_fn_(halo_user_, work_, view, i + 4);
+      }
+      dim0_conv(s, i, in, nullptr, out, nullptr, prof, stream_, H, own, true);
+    }
     std::swap(work_, work2_);
     std::swap(work_nyq_, work2_nyq_);
-    P.axis1(MVN_ST_INV, (cfloat*)work_, nullptr, stream_, prof, stream_);
+    P.axis1(MVN_ST_INV, (cfloat*)work_, nullptr, stream_, prof, stream_, H, own);
     if (halo_fn_ && halo_post_) {  // the slabs merge their reports of non-finite inputs under the dim1 pass
       if (halo_drain_) be::stream_sync(stream_);
-      halo_fn_(halo_user_, work_, (int)(&s - views_.data()), i + 2);
+      halo_fn_(halo_user_, work_, view, i + 2);
     }
     return;
   }
@@ -1028,7 +1085,7 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
   // below MVN_D0_SIDE_MIN_MB (default 256) the Nyquist plane's two dim1 launches cost less in line
   // (256^3 per view update: 0.329 ms with the side stream, 0.312 with the fused FFT pass)
   static const size_t d0_side_min = (size_t)env_int("MVN_D0_SIDE_MIN_MB", 256) << 20;
-  const bool use_side = side && side->s && P.L.even && P.main_bytes() > d0_side_min;
+  const bool use_side = side && side->s && P.L.even && P.main_bytes() > d0_side_min && !P.nyq_rides();
   be::stream_t sn = use_side ? side->s : stream_;
   // MVN_D0_NYQ_SIDE=1: the Nyquist plane's whole chain (dim1, dim0 leg, dim1) on the side stream, one fork
   // and one join per convolution; default: its dim0 leg rides in the main launch, the side stream joins
@@ -1069,6 +1126,7 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
       // nothing else runs on this engine during a blocking set_view: the work volume is the scratch
       work_has_psi_spectrum_ = false;
       prepare_psf(s, i, dk, kd[i], work_, false, stream_);
+      if (s.tap_k[i]) ensure_work2();  // the direct leg's second work volume: allocated here, not inside a sweep
     } catch (...) {
       be::stream_sync(stream_);
       be::dfree(dk);
@@ -1085,6 +1143,7 @@ void Engine::set_view(int v, const float* image, const float* weights, const flo
 void Engine::reserve_views() {
   be::set_device(device_);
   for (size_t v = 0; v < views_.size(); ++v) alloc_view(views_[v]);
+  if (direct_enabled_) ensure_work2();  // (not inside the first sweep: the direct dim0 leg is out of place)
   if (!upload_stream_) upload_stream_ = be::stream_create_upload();
   staged_ev_.resize(views_.size(), nullptr);
   for (size_t v = 0; v < views_.size(); ++v)
@@ -1221,25 +1280,28 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
   SideStream* side = (no_side || P.main_bytes() <= side_min_bytes) ? nullptr : &side_;
   // (work_ / work_nyq_ are re-read after every middle(): the direct dim0 leg swaps the two work volumes)
-  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, (cfloat*)work_, wn(), stream_, prof);
+  // (halo mode: the rows of the own planes only, see middle())
+  const long r0 = halo_ranged() ? (long)halo_planes_ * P.L.d1 : 0;
+  const long nr = halo_ranged() ? (long)(P.L.d0 - 2 * halo_planes_) * P.L.d1 : -1;
+  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, (cfloat*)work_, wn(), stream_, prof, r0, nr);
   work_has_psi_spectrum_ = false;
   middle(s, 0, prof, side);
   arm(e1);
   // view / blurred, handed to convolution 2 as its last-axis spectrum
   if (fuse) {
-    P.rows_c2r_r2c((cfloat*)work_, wn(), e1, stream_, prof);
+    P.rows_c2r_r2c((cfloat*)work_, wn(), e1, stream_, prof, r0, nr);
   } else {
-    P.rows_c2r((const cfloat*)work_, wn(), work_, e1, stream_, prof);
-    P.rows_r2c(work_, (cfloat*)work_, wn(), stream_, prof);
+    P.rows_c2r((const cfloat*)work_, wn(), work_, e1, stream_, prof, r0, nr);
+    P.rows_r2c(work_, (cfloat*)work_, wn(), stream_, prof, r0, nr);
   }
   // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
   middle(s, 1, prof, side);
   arm(e2);
   if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
-    P.rows_c2r_r2c((cfloat*)work_, wn(), e2, stream_, prof);
+    P.rows_c2r_r2c((cfloat*)work_, wn(), e2, stream_, prof, r0, nr);
     work_has_psi_spectrum_ = true;
   } else {
-    P.rows_c2r((const cfloat*)work_, wn(), psi_, e2, stream_, prof);
+    P.rows_c2r((const cfloat*)work_, wn(), psi_, e2, stream_, prof, r0, nr);
   }
 }
 
@@ -1319,6 +1381,20 @@ float* Engine::delta_ptr() {
   return delta_;
 }
 
+// the rows of the own planes start and end on tile boundaries of the last-axis passes
+bool Engine::halo_ranged() const {
+  if (!halo_fn_ || halo_planes_ < 1) return false;
+  if (!plan_->rows_need_full_tiles()) return true;
+  const long T = plan_->rows_tile(), d1 = plan_->L.d1;
+  return ((long)halo_planes_ * d1) % T == 0 && ((long)(plan_->L.d0 - 2 * halo_planes_) * d1) % T == 0;
+}
+
+void Engine::set_halo_planes(int planes, bool split) {
+  if (planes < 0 || 2 * planes >= plan_->L.d0) throw std::invalid_argument("mvn: halo planes must leave own planes");
+  halo_planes_ = planes;
+  halo_split_ = split && planes > 0;
+}
+
 void Engine::set_halo_hook(halo_fn_t fn, void* user, bool drain, bool post) {
   if (fn) {
     if (!plan_->L.even || !mvn_dim0_packed_possible(plan_->L.d0))
@@ -1329,6 +1405,10 @@ void Engine::set_halo_hook(halo_fn_t fn, void* user, bool drain, bool post) {
   halo_user_ = user;
   halo_drain_ = drain;
   halo_post_ = post && fn;
+  if (!fn) {
+    halo_planes_ = 0;
+    halo_split_ = false;
+  }
 }
 
 void Engine::copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer,
@@ -1427,7 +1507,7 @@ void Engine::compute_delta_head(double lambda, float min_value) {
   const bool fuse = P.can_fuse_rows() && !no_fuse;
   static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;
   static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
-  const bool use_side = !no_side && side_.s && P.L.even && P.main_bytes() > side_min_bytes && !packed_;
+  const bool use_side = !no_side && side_.s && P.L.even && P.main_bytes() > side_min_bytes && !packed_ && !P.nyq_rides();
   be::stream_t sn = use_side ? side_.s : stream_;
   if (!psi_spec_valid_) {  // else: left there chunk by chunk by apply_delta_chunk(.., feed_next)
     P.rows_r2c(psi_, (cfloat*)psi_spec_, pn(), stream_, prof);

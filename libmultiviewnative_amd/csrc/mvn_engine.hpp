@@ -105,7 +105,8 @@ class Plan3D {
   DevAxis ax2, ax1, ax0;
   cfloat* twr = nullptr;  // d2-th roots of unity (even d2)
   unsigned* no_poison = nullptr;  // a zero word: what EpilogueParams::poison points to after an FFT dim0 leg
-  PassGeom g_rows, g_ax1, g_ax0, g_ax0f, g_nyq1, g_nyq0;
+  PassGeom g_rows, g_ax1, g_ax0, g_ax0f, g_nyq1, g_nyq0, g_nyq1_line;
+  bool nyq_rides() const;
   // compile-time specialised kernels (mvn_fixed.hpp) are used where the shape allows
   bool fx_rows = false, fx_ax1 = false, fx_ax0 = false;
   PassGeom gx_rows, gx_ax1, gx_ax0;
@@ -133,7 +134,7 @@ class Plan3D {
   // (data, nyq); epi.mode is DIVIDE, UPDATE or STORE
   bool can_fuse_rows() const { return L.even; }
   void rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, be::stream_t s,
-                    Profiler* prof = nullptr) const;
+                    Profiler* prof = nullptr, long row0 = 0, long nrows = -1) const;
   // strided passes on the main array and its Nyquist plane; mode = MvnStridedMode
   // `s_nyq` (default: s) is the stream of the small Nyquist-plane launches; giving them their own
   // stream lets the 2 MB plane ride along with the full-volume passes (see SideStream)
@@ -283,6 +284,13 @@ class Engine {
   // post: fn is called a second time right AFTER the leg has been enqueued, with conv + 2 - where the ranks merge
   // their poison words (a non-finite input met by ONE slab's leg must turn EVERY slab's volume into NaN)
   void set_halo_hook(halo_fn_t fn, void* user, bool drain = true, bool post = false);
+  // Tells the engine how many planes at either end of its volume are halo planes (after set_halo_hook): no pass
+  // computes them any more - the last-axis and dim1 passes and the leg run on the own planes only (where those
+  // start and end on tile boundaries of the last-axis passes; otherwise everything is computed as before).
+  // split: the leg runs in two parts, the own planes that do not depend on the halos first, and fn is called
+  // once more in between, with conv + 4 - the halo planes need to be in place only behind THAT call, so that an
+  // exchange started at the first call runs beside the first part.
+  void set_halo_planes(int planes, bool split);
   // The poison word (mvn_dim0_direct.hpp, EpilogueParams::poison): a direct dim0 leg that met a non-finite input
   // stores its epoch there.  poison_ptr(): the device word; bind_poison(): use caller-owned device memory (4 bytes,
   // zeroed) instead, e.g. a torch tensor a collective can MAX-reduce in place; poison_get() drains the stream and
@@ -296,6 +304,7 @@ class Engine {
   void clear_poison_peers() { poison_peers_.clear(); }  // (the device table is only read up to n_peers)
   // slabs of one volume on several engines count their direct legs together: same epoch for the same leg
   unsigned poison_epoch() const { return epoch_; }
+  void set_poison_epoch(unsigned e) { epoch_ = e; }
   void copy_planes(void* spectrum, int plane0, int nplanes, void* buffer, bool to_buffer, bool host_buffer = false,
                    bool wait = true);
   float* psi_ptr() { return psi_; }
@@ -350,8 +359,9 @@ class Engine {
   Plan3D* taps_plan(int kd);
   // dim1 forward -> dim0 leg (direct or fused FFT) -> dim1 inverse on the work volume, with kernel i of s
   void middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side);
+  // zcount > 0: only the output planes [zbeg, zbeg + zcount); first = false: a further launch of the same leg
   void dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out, cfloat* out_nyq,
-                 Profiler* prof, be::stream_t sn);
+                 Profiler* prof, be::stream_t sn, int zbeg = 0, int zcount = 0, bool first = true);
   void ensure_work2();
   // Nyquist layout of the spectra between the last-axis passes of one call (mvn_dim0_direct.hpp, RowsParams::
   // nyq_packed): packed into the DC column when every kernel of every view is in the direct form, else the
@@ -363,7 +373,9 @@ class Engine {
   bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
   halo_fn_t halo_fn_ = nullptr;
   void* halo_user_ = nullptr;
-  bool halo_drain_ = true, halo_post_ = false;
+  bool halo_drain_ = true, halo_post_ = false, halo_split_ = false;
+  int halo_planes_ = 0;
+  bool halo_ranged() const;
   unsigned* poison_ = nullptr;      // the word in use: poison_own_, or caller-owned memory (bind_poison)
   unsigned* poison_own_ = nullptr;  // 256 bytes: [0] the engine's own word, byte 64: table of the peers' words
   std::vector<unsigned*> poison_peers_;

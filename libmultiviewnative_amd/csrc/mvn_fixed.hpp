@@ -677,8 +677,8 @@ MVN_HD void fx_strided_body(const StridedParams& P, long first, long total, long
 template <int N>
 struct FxFusedCfg {
   typedef FxStridedCfg<N> S;
-#ifdef MVN_FX_NO_LDS_FUSED
-  static constexpr bool USE = false;  // experiment: register-staged body for every length
+#if defined(MVN_EXPERIMENTS) && defined(MVN_FX_NO_LDS_FUSED)
+  static constexpr bool USE = false;  // experiment (variant builds only): register-staged body for every length
 #else
   static constexpr bool USE = S::WG_PER_CU >= 2;
 #endif
@@ -1440,13 +1440,13 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
   MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
-#ifndef MVN_EXP_SKIP_PREPOST  // timing experiment only (wrong results): what two LDS round trips cost
+#if !(defined(MVN_EXPERIMENTS) && defined(MVN_EXP_SKIP_PREPOST))  // timing experiment (variant builds only, WRONG results): what two LDS round trips cost
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
 #endif
   fx_dit<H, T, TP, C::PAD, NT, +1, 1, C::TWT>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, true, EPI>(P, r0, buf, tws, r, tid)));
   fx_dif<H, T, TP, C::PAD, NT, -1, 1, C::TWT>(buf, tws, ctx);
-#ifndef MVN_EXP_SKIP_PREPOST
+#if !(defined(MVN_EXPERIMENTS) && defined(MVN_EXP_SKIP_PREPOST))
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
 #endif
   MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));

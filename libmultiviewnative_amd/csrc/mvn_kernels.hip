@@ -29,6 +29,12 @@
 #include <stdexcept>
 #include <string>
 
+// Every switch that changes what a kernel computes or how much LDS it asks for - timing experiments - is compiled
+// only with -DMVN_EXPERIMENTS, which `make all` never sets (`make probe` / `make variant EXTRA=..` do);
+// tests/test_abi_symbols.py checks the product library for their traces.
+#if defined(MVN_PROBE) && !defined(MVN_EXPERIMENTS)
+#error "MVN_PROBE is a timing experiment: build it with -DMVN_EXPERIMENTS (make probe)"
+#endif
 #ifdef MVN_PROBE
 // Timing probe (never in the product build): every workgroup works on tile (index mod wrap), so the
 // working set of a pass is a few MB that stay in the L2 / Infinity Cache -- what a pass costs when
@@ -130,25 +136,41 @@ __global__ void __launch_bounds__(WrCfg::NT, 4) kw_rows(const RowsParams p0) {
   wr_rows_body<MODE, EPI>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
+// `main_grid` walking workgroups work on the main array; the workgroups behind them (plain dim1 passes only) take
+// ONE line of the Nyquist plane each - 4 KB at 512 points, through the run-time-radix body - so that the plane
+// needs no launch, stream and fork / join pair of its own: 512 two-microsecond workgroups that fill the slots
+// the walkers leave at the end of the launch, instead of 32 workgroups of 16 lines that queued for a slot beside
+// the next full-volume pass on a second hardware queue (round 3: 25 % of all GPU-busy time for 0.4 % of the bytes).
 template <int N, int MODE>
 __global__ void __launch_bounds__((FxStridedSel<N, MODE>::NT), (FxStridedSel<N, MODE>::WAVES))
-    kx_strided(const StridedParams p) {
+    kx_strided(const StridedParams p, const StridedParams rider, unsigned main_grid) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  if constexpr (MODE != MVN_ST_FWD_MUL_INV) {
+    if (blockIdx.x >= main_grid) {
+      strided_body<MODE, 1, true>(rider, (long)(blockIdx.x - main_grid), (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+      return;
+    }
+  }
   typename FxStridedSel<N, MODE>::Ctx ctx;
   ctx.tid = (int)threadIdx.x;
-  FxStridedSel<N, MODE>::run(p, (long)blockIdx.x, p.nblocks, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
+  FxStridedSel<N, MODE>::run(p, (long)blockIdx.x, p.nblocks, (long)main_grid, (cfloat*)mvn_smem, ctx);
 }
 
 template <int N, int MODE>
-__global__ void __launch_bounds__((FxSplitCfg<N>::NT)) kx_strided_split(const StridedParams p) {
+__global__ void __launch_bounds__((FxSplitCfg<N>::NT)) kx_strided_split(const StridedParams p, const StridedParams rider,
+                                                                       unsigned main_grid) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  if (blockIdx.x >= main_grid) {
+    strided_body<MODE, 1, true>(rider, (long)(blockIdx.x - main_grid), (int)threadIdx.x, (int)blockDim.x, (cfloat*)mvn_smem);
+    return;
+  }
   FxCtx<FxSplitRegs<N>, FxSplitCfg<N>::NT> ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_strided_split_body<N, MODE>(p, (long)blockIdx.x, p.nblocks, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
+  fx_strided_split_body<N, MODE>(p, (long)blockIdx.x, p.nblocks, (long)main_grid, (cfloat*)mvn_smem, ctx);
 }
 
 // direct dim0 convolution (mvn_dim0_direct.hpp): one bin per work item, all of dim0
-// (K = 25 sits one register above the 128 that let four waves share a SIMD: bounded there)
+// (K = 25 sits a register or two above the 128 that let four waves share a SIMD: bounded there)
 template <int K, int PF = MVN_D0_PF>
 __global__ void __launch_bounds__(MVN_D0_WG, (K == 25 ? 4 : 1)) kd_dim0(const Dim0DirectParams p, unsigned main_blocks) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
@@ -320,6 +342,29 @@ void d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t wid
 }
 void dzero(void* d, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(d, 0, bytes, hs(s))); }
 
+void enable_peer_access(int dev, int peer) {
+  if (dev == peer) return;
+  int can = 0;
+  HIP_CHECK(hipDeviceCanAccessPeer(&can, dev, peer));
+  if (!can) throw std::runtime_error("mvn: device " + std::to_string(dev) + " cannot access device " + std::to_string(peer));
+  int cur = 0;
+  HIP_CHECK(hipGetDevice(&cur));
+  HIP_CHECK(hipSetDevice(dev));
+  const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+  (void)hipSetDevice(cur);
+  if (e == hipErrorPeerAccessAlreadyEnabled) {
+    (void)hipGetLastError();
+    return;
+  }
+  HIP_CHECK(e);
+}
+void copy_peer(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, stream_t s) {
+  if (dst_dev == src_dev)
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, hs(s)));
+  else
+    HIP_CHECK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, hs(s)));
+}
+
 stream_t stream_create() {
   hipStream_t s;
   HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -481,7 +526,8 @@ static int resident_per_cu(const void* kernel, int nthreads, size_t lds_bytes) {
 
 template <typename K>
 static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads, size_t lds_bytes,
-                           stream_t s, bool walk) {
+                           stream_t s, bool walk, const StridedParams* rider = nullptr, size_t rider_lds = 0) {
+  if (rider && rider_lds > lds_bytes) lds_bytes = rider_lds;
   ensure_lds(kernel, lds_bytes);
   static const int mode = [] {
     const char* e = std::getenv("MVN_PERSIST");
@@ -494,7 +540,10 @@ static void launch_walking(K kernel, StridedParams p, long nblocks, int nthreads
     if (grid > resident) grid = resident;
   }
   p.nblocks = nblocks;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(nthreads), lds_bytes, hs(s), p);
+  const long lines = rider ? rider->tiles_per_outer : 0;  // one line of the Nyquist plane per workgroup
+  if (grid + lines > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid + lines)), dim3(nthreads), lds_bytes, hs(s), p, rider ? *rider : p,
+                     (unsigned)grid);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -528,10 +577,11 @@ static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
 // at 32; MVN_WR_GRID_MULT overrides both.
 template <typename K>
 static void launch_wave_rows(K kernel, const RowsParams& p, stream_t s, long mult_default = 16) {
-  static const size_t pad = [] {  // experiment knob: extra LDS per workgroup = fewer resident workgroups
-    const char* e = std::getenv("MVN_WR_LDS_PAD_KB");
-    return (size_t)(e && *e ? std::atoi(e) : 0) * 1024;
-  }();
+#if defined(MVN_EXPERIMENTS) && defined(MVN_WR_LDS_PAD_KB)  // variant builds only: extra LDS = fewer resident workgroups
+  const size_t pad = (size_t)MVN_WR_LDS_PAD_KB * 1024;
+#else
+  const size_t pad = 0;
+#endif
   const size_t lds = sizeof(cfloat) * (size_t)WrCfg::lds_cfloats + pad;
   const long pairs = (p.rows + 1) / 2;
   long grid = (pairs + WrCfg::WAVES - 1) / WrCfg::WAVES;
@@ -673,7 +723,8 @@ long split_launch_count() { return g_split_launches.load(); }
 // long lines: 16-column tiles through the split-window body when the columns divide (the plan's
 // geometry is for the 8-column kernel); MVN_NO_SPLIT=1 keeps the 8-column kernel
 template <int N>
-static bool try_launch_split(int mode, const StridedParams& p, long nblocks, stream_t s) {
+static bool try_launch_split(int mode, const StridedParams& p, long nblocks, stream_t s, const StridedParams* rider,
+                             size_t rider_lds) {
   if constexpr (FxSplitCfg<N>::USE) {
     typedef FxSplitCfg<N> C;
     static const bool off = [] {
@@ -696,28 +747,30 @@ static bool try_launch_split(int mode, const StridedParams& p, long nblocks, str
     const size_t lds = sizeof(cfloat) * (size_t)C::lds_cfloats;
     ++g_split_launches;
     if (mode == MVN_ST_FWD)
-      launch_walking(kx_strided_split<N, MVN_ST_FWD>, q, nb, C::NT, lds, s, true);
+      launch_walking(kx_strided_split<N, MVN_ST_FWD>, q, nb, C::NT, lds, s, true, rider, rider_lds);
     else
-      launch_walking(kx_strided_split<N, MVN_ST_INV>, q, nb, C::NT, lds, s, true);
+      launch_walking(kx_strided_split<N, MVN_ST_INV>, q, nb, C::NT, lds, s, true, rider, rider_lds);
     return true;
   } else {
-    (void)mode; (void)p; (void)nblocks; (void)s;
+    (void)mode; (void)p; (void)nblocks; (void)s; (void)rider; (void)rider_lds;
     return false;
   }
 }
 
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
-                    size_t lds_bytes, stream_t s) {
+                    size_t lds_bytes, stream_t s, const StridedParams* rider, size_t rider_lds) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (rider && (!p.fixed || mode == MVN_ST_FWD_MUL_INV || rider->T != 1 || rider->fixed || rider_lds > 160 * 1024))
+    throw std::invalid_argument("mvn: Nyquist lines ride only in the plain fixed-length strided passes, one per workgroup");
   if (p.fixed) {
     check_aligned16(p.data, "data");
     if (mode == MVN_ST_FWD_MUL_INV) check_aligned16(p.spec, "spectrum");
     switch (p.ax.n) {
 #define X(N)                                                                                       \
   case N:                                                                                          \
-    if (try_launch_split<N>(mode, p, nblocks, s)) return;                                          \
-    if (mode == MVN_ST_FWD) launch_walking(kx_strided<N, MVN_ST_FWD>, p, nblocks, FxStridedSel<N, MVN_ST_FWD>::NT, lds_bytes, s, true); \
-    else if (mode == MVN_ST_INV) launch_walking(kx_strided<N, MVN_ST_INV>, p, nblocks, FxStridedSel<N, MVN_ST_INV>::NT, lds_bytes, s, true); \
+    if (try_launch_split<N>(mode, p, nblocks, s, rider, rider_lds)) return;                        \
+    if (mode == MVN_ST_FWD) launch_walking(kx_strided<N, MVN_ST_FWD>, p, nblocks, FxStridedSel<N, MVN_ST_FWD>::NT, lds_bytes, s, true, rider, rider_lds); \
+    else if (mode == MVN_ST_INV) launch_walking(kx_strided<N, MVN_ST_INV>, p, nblocks, FxStridedSel<N, MVN_ST_INV>::NT, lds_bytes, s, true, rider, rider_lds); \
     else launch_walking(kx_strided<N, MVN_ST_FWD_MUL_INV>, p, nblocks, FxStridedSel<N, MVN_ST_FWD_MUL_INV>::NT, lds_bytes, s, !FxStridedSel<N, MVN_ST_FWD_MUL_INV>::ONE_TILE); \
     return;
       MVN_FIXED_STRIDED_LENGTHS(X)
@@ -759,6 +812,9 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
     if (lds > 64 * 1024) throw std::invalid_argument("mvn: dim0 too long for the packed DC column");
   }
   if (nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
+#if defined(MVN_EXPERIMENTS) && defined(MVN_D0_LDS_PAD_KB)  // variant builds only: bounds the workgroups per CU through their LDS
+  if (lds < (size_t)MVN_D0_LDS_PAD_KB * 1024) lds = (size_t)MVN_D0_LDS_PAD_KB * 1024;
+#endif
   switch (mvn_dim0_taps_template(p.k)) {
 #define X(K) case K: hipLaunchKernelGGL(kd_dim0<K>, dim3((unsigned)nblocks), dim3(MVN_D0_WG), lds, hs(s), p, (unsigned)main_blocks); break;
     MVN_D0_TAP_COUNTS(X)

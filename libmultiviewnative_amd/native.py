@@ -29,14 +29,14 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_get_pad_mode", "mvn_release_cached_engines", "mvn_deconvolve_submit", "mvn_deconvolve_wait", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_get_pad_mode", "mvn_release_cached_engines", "mvn_deconvolve_submit", "mvn_deconvolve_wait", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_multi_device_calls", "mvn_group_create", "mvn_group_destroy", "mvn_group_load", "mvn_group_iterate", "mvn_group_get_psi", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
     "mvn_engine_compute_delta", "mvn_engine_apply_delta", "mvn_engine_delta_ptr",
     "mvn_engine_delta_chunks", "mvn_engine_delta_chunk_range", "mvn_engine_compute_delta_head",
     "mvn_engine_compute_delta_chunk", "mvn_engine_apply_delta_chunk",
-    "mvn_engine_bind_delta", "mvn_engine_set_halo_hook", "mvn_engine_poison_ptr", "mvn_engine_bind_poison", "mvn_engine_poison_get", "mvn_engine_poison_merge", "mvn_engine_copy_planes", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
+    "mvn_engine_bind_delta", "mvn_engine_set_halo_hook", "mvn_engine_set_halo_planes", "mvn_engine_would_be_direct", "mvn_engine_poison_ptr", "mvn_engine_bind_poison", "mvn_engine_poison_get", "mvn_engine_poison_merge", "mvn_engine_copy_planes", "mvn_engine_psi_ptr", "mvn_engine_stream", "mvn_engine_sync", "mvn_engine_time_iterate",
     "mvn_engine_profile", "mvn_engine_profile_read", "mvn_kernel_kind_count",
     "mvn_kernel_kind_name", "mvn_engine_B",
     "mvn_slab_create", "mvn_slab_destroy", "mvn_slab_set_view", "mvn_slab_set_psi", "mvn_slab_get_psi",
@@ -67,6 +67,14 @@ class Binding:
         l.mvn_backend_name.restype = C.c_char_p
         l.mvn_split_launch_count.restype = C.c_long
         l.mvn_split_launch_count.argtypes = []
+        l.mvn_multi_device_calls.restype = C.c_long
+        l.mvn_multi_device_calls.argtypes = []
+        l.mvn_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p)]
+        l.mvn_group_destroy.argtypes = [C.c_void_p]
+        l.mvn_group_load.argtypes = [C.c_void_p, C.POINTER(C.c_float), Workspace]
+        l.mvn_group_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_float, C.POINTER(C.c_float)]
+        l.mvn_group_get_psi.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.mvn_kernel_kind_name.restype = C.c_char_p
         l.mvn_kernel_kind_name.argtypes = [C.c_int]
         l.mvn_set_pad_mode.argtypes = [C.c_char_p]
@@ -125,6 +133,8 @@ class Binding:
         l.mvn_engine_bind_delta.argtypes = [C.c_void_p, C.c_void_p]
         l.mvn_engine_set_halo_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         l.mvn_engine_copy_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        l.mvn_engine_set_halo_planes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.mvn_engine_would_be_direct.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         l.mvn_engine_poison_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         l.mvn_engine_bind_poison.argtypes = [C.c_void_p, C.c_void_p]
         l.mvn_engine_poison_get.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
@@ -310,6 +320,51 @@ class Binding:
     def slab_engine(self, shape, nranks, rank, num_views, device=0):
         return SlabHandle(self, shape, nranks, rank, num_views, device)
 
+    def group(self, devices, shape, halo_planes, num_views):
+        return GroupHandle(self, devices, shape, halo_planes, num_views)
+
+
+class GroupHandle:
+    """One volume as dim0 slabs on several devices of this process (``mvn_group_*``; what MVN_DEVICES runs inside
+    ``inplace_gpu_deconvolve``), stacks resident between ``load`` and ``get_psi``."""
+
+    def __init__(self, binding, devices, shape, halo_planes, num_views):
+        self.b = binding
+        self.shape = tuple(int(s) for s in shape)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        binding.check(binding.l.mvn_group_create(devs, len(devices), _dims(shape), int(halo_planes), int(num_views),
+                                                 C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.b.l.mvn_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, psi, holder):
+        """psi and the stacks of a ``WorkspaceHolder`` (extents == the group's)"""
+        psi = np.ascontiguousarray(psi, dtype=np.float32)
+        assert psi.shape == self.shape
+        self.b.check(self.b.l.mvn_group_load(self.h, fptr(psi), holder.ws))
+
+    def iterate(self, iterations, lam, min_value):
+        """blocking; returns the wall time of the sweeps in ms"""
+        ms = C.c_float(0)
+        self.b.check(self.b.l.mvn_group_iterate(self.h, int(iterations), float(lam), float(min_value), C.byref(ms)))
+        return ms.value
+
+    def get_psi(self):
+        out = np.empty(self.shape, np.float32)
+        self.b.check(self.b.l.mvn_group_get_psi(self.h, fptr(out)))
+        return out
+
 
 class EngineHandle:
     """Resident RL engine (``mvn_engine_*``)."""
@@ -409,6 +464,15 @@ class EngineHandle:
         self._halo_cb = self.HALO_FN(lambda user, spectrum, view, conv: fn(spectrum, view, conv))
         self.b.check(self.b.l.mvn_engine_set_halo_hook(self.h, C.cast(self._halo_cb, C.c_void_p), None,
                                                        (1 if drain else 0) | (2 if post else 0)))
+
+    def would_be_direct(self, kernel_shape):
+        rc = self.b.l.mvn_engine_would_be_direct(self.h, _dims(kernel_shape))
+        if rc < 0:
+            self.b.check(rc)
+        return rc == 1
+
+    def set_halo_planes(self, planes, split=False):
+        self.b.check(self.b.l.mvn_engine_set_halo_planes(self.h, int(planes), 1 if split else 0))
 
     def bind_poison(self, dev_ptr):
         self.b.check(self.b.l.mvn_engine_bind_poison(self.h, C.c_void_p(dev_ptr)))

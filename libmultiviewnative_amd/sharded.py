@@ -228,6 +228,7 @@ class HaloSlabDriver:
         if self.ext is not None:
             self.eng.bind_poison(self.flag.data_ptr())
         self.eng.set_halo_hook(self._exchange, drain=self.ext is None, post=self.dist is not None)
+        self.eng.set_halo_planes(self.h)  # the halo planes are the neighbours': no pass of this engine computes them
 
     # --- data in / out: the caller hands over its own planes [z0, z0 + nz) ----------------------------------
     def _extend(self, local, fill):
@@ -239,6 +240,10 @@ class HaloSlabDriver:
     def set_view(self, v, image_local, weights_local, kernel1, kernel2):
         if max(kernel1.shape[0], kernel2.shape[0]) // 2 > self.h:
             raise ValueError("halo mode: PSF deeper than the halo this driver was created for")
+        for k in (kernel1, kernel2):  # refused here, not by an engine that throws in the middle of a sweep
+            if not self.eng.would_be_direct(k.shape):
+                raise ValueError("halo mode: a PSF of extents %s is not held in the direct dim0 form (at most 33 "
+                                 "planes along dim0)" % (tuple(k.shape),))
         self.eng.set_view(v, self._extend(image_local, 1.0), self._extend(weights_local, 0.0), kernel1, kernel2)
 
     def set_psi(self, psi_local):

@@ -103,3 +103,21 @@ def test_bench_keeps_foreign_output_off_stdout():
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip() == '{"ok": true}', r.stdout
     assert "python-level noise" in r.stderr and "c-level noise" in r.stderr
+
+
+def test_product_build_has_no_timing_experiment_switches():
+    # switches that change what a kernel computes (some give WRONG results) or how much LDS it
+    # asks for are timing experiments; they compile only under -DMVN_EXPERIMENTS, which the product target never sets
+    csrc = os.path.join(ROOT, "libmultiviewnative_amd", "csrc")
+    plan = subprocess.check_output(["make", "-n", "-B", "-C", csrc, "all"]).decode()
+    assert "libmultiviewnative.so" in plan and "MVN_EXPERIMENTS" not in plan and "MVN_PROBE" not in plan
+    blob = open(native.PRODUCT_SO, "rb").read()
+    for trace in (b"MVN_WR_LDS_PAD_KB", b"MVN_PROBE_WRAP", b"MVN_EXP_", b"MVN_D0_LDS_PAD"):
+        assert trace not in blob, trace
+    # every experiment switch in the sources sits behind the one define
+    for name in os.listdir(csrc):
+        if not name.endswith((".hpp", ".hip", ".cpp")):
+            continue
+        for line in open(os.path.join(csrc, name)):
+            if re.match(r"\s*#\s*if", line) and re.search(r"MVN_(EXP_|FX_NO_LDS_FUSED|WR_LDS_PAD_KB|D0_LDS_PAD_KB)", line):
+                assert "MVN_EXPERIMENTS" in line, (name, line)

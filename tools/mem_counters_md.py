@@ -12,7 +12,12 @@ import rocpd_stats
 KERNELS = [("kx_rows_r2c<256>", "rows_r2c", 2.0), ("kx_strided<512, 0>", "axis1_fwd", 2.0),
            ("kx_strided<512, 1>", "axis1_inv", 2.0), ("kx_strided<512, 2>", "axis0_fused", 3.0),
            ("kd_dim0<31, 4>", "axis0_direct", 2.06),
-           ("kw_rows<2, 1>", "rows_fused_div", 3.0), ("kw_rows<2, 2>", "rows_fused_upd", 5.0)]
+           ("kw_rows<2, 1>", "rows_fused_div", 3.0), ("kw_rows<2, 2>", "rows_fused_upd", 5.0),
+           # configs[4]'s extents (1920 x 1920 planes)
+           ("kx_rows_r2c<960>", "rows_r2c 960", 2.0), ("kx_strided_split<1920, 0>", "axis1_fwd 1920", 2.0),
+           ("kx_strided_split<1920, 1>", "axis1_inv 1920", 2.0), ("kx_strided<1920, 0>", "axis1_fwd 1920 (8 col)", 2.0),
+           ("kx_rows_c2r_r2c<960, 1>", "rows_fused_div 960", 3.0), ("kx_rows_c2r_r2c<960, 2>", "rows_fused_upd 960", 5.0),
+           ("kd_dim0<15, 4>", "axis0_direct K=15", 2.06)]
 
 
 def main():

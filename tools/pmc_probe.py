@@ -7,7 +7,8 @@ lib = native.lib()
 shape = tuple(int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (512, 512, 512)))
 rng = np.random.default_rng(0)
 eng = lib.engine(shape, 1)
-k = np.zeros((31, 31, 31), np.float32); k[15, 15, 15] = 0.5; k[14, 15, 15] = 0.25; k[16, 15, 15] = 0.25  # 31 planes: the headline's depth
+kd = min(31, shape[0] if shape[0] >= 35 else 15, shape[0])  # 31 planes (the headline's depth) where the volume allows
+k = np.zeros((kd, 31, 31), np.float32); k[kd // 2, 15, 15] = 0.5; k[kd // 2 - 1, 15, 15] = 0.25; k[kd // 2 + 1, 15, 15] = 0.25
 eng.set_view(0, rng.uniform(10, 20, shape).astype(np.float32), np.full(shape, 0.5, np.float32), k, k)
 eng.set_psi(np.full(shape, 15.0, np.float32))
 eng.iterate(3, 0.006, 1e-4)

@@ -248,22 +248,17 @@ def exact_halo_mode(lib, devices, shape, psf_edge, n_views, steps, warmup, check
            "devices": list(devices), "value": round(steps / (ms * 1e-3), 4), "unit": "iterations/s",
            "ms_per_step": round(ms / steps, 4), "steps": steps, "warmup": warmup,
            "psi_finite_positive": bool(np.isfinite(got).all() and (got > 0).all())}
-    # (the slabs keep the Nyquist bins packed in the DC column; the one-device engine does so by itself only up to
-    # 256 MB per volume - asked to, it runs the same arithmetic and the comparison is bit for bit)
-    packed_before = os.environ.get("MVN_NYQ_PACKED")
-    os.environ["MVN_NYQ_PACKED"] = "1"
-    try:
-        e = lib.engine(shape, n_views, device=check_device)
-    finally:
-        if packed_before is None:
-            os.environ.pop("MVN_NYQ_PACKED", None)
-        else:
-            os.environ["MVN_NYQ_PACKED"] = packed_before
+    # (the slabs run the Nyquist layout the whole volume has on one device: the same arithmetic, bit for bit)
+    e = lib.engine(shape, n_views, device=check_device)
     try:
         for v in range(n_views):
             e.set_view(v, views[v], w, k1s[v], k2s[v])
         e.set_psi(psi0)
-        e.iterate(warmup + steps, LAMBDA, MIN_VALUE, sync=True)
+        # (in the same two calls as the group: the last view update of a call ends in the plain c2r pass, every
+        # other one in the fused c2r + r2c pass - the same values up to the rounding of two different kernels)
+        if warmup > 0:
+            e.iterate(warmup, LAMBDA, MIN_VALUE, sync=True)
+        e.iterate(steps, LAMBDA, MIN_VALUE, sync=True)
         one = e.get_psi()
     finally:
         e.close()
@@ -271,6 +266,40 @@ def exact_halo_mode(lib, devices, shape, psf_edge, n_views, steps, warmup, check
                      "bit_equal": bool(np.array_equal(got, one)),
                      "max_rel": float(np.abs(got.astype(np.float64) - one).max() / np.abs(one).max())}
     return out
+
+
+def measured_traffic(kind, shape):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected NOW: two rocprofv3 passes
+    (FETCH_SIZE; WRITE_SIZE) of child processes that run tools/pmc_probe.py on this GPU, corrected as
+    MI355X_MICROARCH.md's HBM section prescribes (counters in KiB, read side x 2 on gfx950) by
+    tools/pmc_summarize.py.  None when rocprofv3 is not there or a pass fails - the static record is used then."""
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None or tuple(shape) != (512, 512, 512):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summarize
+    tmp = tempfile.mkdtemp(prefix="mvn_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for sub, counters in (("rd", ["FETCH_SIZE"]), ("wr", ["WRITE_SIZE", "GRBM_GUI_ACTIVE"])):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + [
+                "-d", os.path.join(tmp, sub), "-o", "p", "--output-format", "csv", "--",
+                sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+            if r.returncode != 0:
+                return None
+        rd, rn = pmc_summarize.read(os.path.join(tmp, "rd"), "FETCH_SIZE")
+        wr, wn = pmc_summarize.read(os.path.join(tmp, "wr"), "WRITE_SIZE")
+        for name in rd:
+            short = name.replace("void ", "").split("(")[0]
+            if kind in pmc_summarize.KINDS.get(short, []) and rn[name] and wn.get(name):
+                return (2.0 * rd[name] / rn[name] + wr[name] / wn[name]) * 1024.0
+        return None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -440,6 +469,8 @@ def run_rank(args, world_env):
             if os.path.exists(traffic_file) and shape == (512, 512, 512):  # PMC passes were taken at 512^3
                 try:
                     roofline["traffic"] = json.load(open(traffic_file)).get(kind)
+                    roofline["traffic_source"] = ("static: profiles/pmc_traffic.json (PMC passes of tools/profile_round.sh "
+                                                  "over tools/pmc_probe.py, builder-run)")
                 except Exception:
                     pass
         _, B = kernel_bytes("nyquist", d0, d1, d2)
@@ -513,6 +544,12 @@ def run_rank(args, world_env):
 
     if rank == 0 and not args.no_side and (world == 1 or args.check_parity):
         try:
+            if world == 1 and out.get("roofline") and not args.no_abi:
+                live = measured_traffic(out["roofline"]["kernel"], shape)  # (the engine is closed: the GPU is free)
+                if live:
+                    out["roofline"]["traffic"] = live
+                    out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                         "over tools/pmc_probe.py on this GPU (read side x 2 on gfx950)")
             if world == 1:
                 out["ms_per_fft"] = round(lib.fft3_time(shape, 0, 10, device=local_rank), 4)
             parity, cpu = one_view_check(lib, shape, psf_edge, V, psi, local_rank, not args.no_cpu_baseline)

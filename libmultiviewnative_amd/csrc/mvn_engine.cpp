@@ -661,19 +661,21 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 131072);  // see direct_ok_for()
   direct_min_items_ = env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
   d0_stagger_ = env_int("MVN_D0_STAGGER", 64);
-  // Packed Nyquist layout (mvn_dim0_direct.hpp): MVN_NYQ_PACKED = 1 always / 0 never / unset: for volumes up to
-  // MVN_NYQ_PACKED_MAX_MB (default 256).  Small volumes are bound by launches and the Nyquist plane's 4 launches
-  // per view update are a fifth of their time (one view update: 256^3 0.291 -> 0.244 ms, 288^3 0.474 -> 0.421,
-  // 384^3 1.009 -> 0.968); at 512^3 the loop runs at the package power cap and the layout is 2 - 4 % SLOWER
-  // (13.1 - 13.4 against 12.85 ms per 6-view iteration: with the gaps gone the clock-sensitive passes lose more
-  // than the launches cost; profiles/r03_ab_packed_nyquist.txt, r03_power.md)
-  {
-    const int sw = env_int("MVN_NYQ_PACKED", -1);
-    const size_t max_bytes = (size_t)env_int("MVN_NYQ_PACKED_MAX_MB", 256) << 20;
-    packed_allowed_ = (sw > 0 || (sw < 0 && plan_->main_bytes() <= max_bytes)) && mvn_dim0_packed_possible(dims[0]);
-  }
+  packed_allowed_ = packed_layout_for(plan_->main_bytes()) && mvn_dim0_packed_possible(dims[0]);
   for (int d = 0; d < 3; ++d) host_dims_[d] = dims[d];
   be::stream_sync(stream_);
+}
+
+// Packed Nyquist layout (mvn_dim0_direct.hpp): MVN_NYQ_PACKED = 1 always / 0 never / unset: for volumes up to
+// MVN_NYQ_PACKED_MAX_MB (default 256).  Small volumes are bound by launches and latency and the layout's single
+// launch chain wins (one view update, round 4, against the split layout with its Nyquist lines riding in the dim1
+// launches: 64^3 0.055 / 0.062 ms, 128^3 0.082 / 0.089, 256^3 0.246 / 0.262; 320^3 and 384^3 even).  At 512^3 it
+// is 6 % SLOWER (2.24 / 2.11 ms): the DC column's 2 x 257 dim0 columns are 8-byte accesses one row apart in every
+// plane, and the leg takes 0.27 instead of 0.23 ms (profiles/r04_layouts.md).
+bool Engine::packed_layout_for(size_t volume_bytes) {
+  const int sw = env_int("MVN_NYQ_PACKED", -1);
+  const size_t max_bytes = (size_t)env_int("MVN_NYQ_PACKED_MAX_MB", 256) << 20;
+  return sw > 0 || (sw < 0 && volume_bytes <= max_bytes);
 }
 
 Engine::~Engine() {
@@ -1004,7 +1006,8 @@ bool Engine::all_direct() const {
 }
 
 void Engine::decide_layout() {
-  const bool want = packed_allowed_ && plan_->L.even && plan_->nyq_bytes() > 0;
+  const bool allowed = layout_override_ < 0 ? packed_allowed_ : (layout_override_ > 0 && mvn_dim0_packed_possible(plan_->L.d0));
+  const bool want = allowed && plan_->L.even && plan_->nyq_bytes() > 0;
   const bool was = packed_;
   packed_ = want && (pipelined_ ? packed_hint_ : all_direct());
   if (was != packed_) ++graph_gen_;  // ... and the layout
@@ -1028,9 +1031,14 @@ bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
 
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {
   const Plan3D& P = *plan_;
-  if (packed_) {
-    // no Nyquist plane, no second stream: three launches on stream_
+  // One launch chain on stream_ - dim1 forward, direct leg, dim1 inverse, three launches - wherever the Nyquist bins
+  // need no launches of their own: packed into the DC column, or (split layout) riding in the dim1 launches and in
+  // the leg's.
+  const bool one_chain = packed_ || (s.tap_k[i] != 0 && (!P.L.even || P.nyq_rides()));
+  if (one_chain) {
     if (!s.tap_k[i]) throw std::logic_error("mvn: packed Nyquist layout with a kernel that is not in the direct form");
+    if (halo_fn_ && !packed_ && !halo_nyq_aware_)
+      throw std::logic_error("mvn: this halo hook exchanges the main array only: it needs the packed Nyquist layout");
     // Halo mode: the first and last H planes of the volume are the neighbours'.  No pass computes them - the
     // last-axis and dim1 passes run on the own planes [H, d0 - H) only, the leg produces only those - and the leg
     // runs in two parts: the planes that do not depend on the halos first, so that the exchange (the hook's
@@ -1038,36 +1046,38 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
     const int H = halo_ranged() ? halo_planes_ : 0;
     const int own = P.L.d0 - 2 * H;
     const int view = (int)(&s - views_.data());
-    P.axis1(MVN_ST_FWD, (cfloat*)work_, nullptr, stream_, prof, stream_, H, own);
+    P.axis1(MVN_ST_FWD, (cfloat*)work_, wn(), stream_, prof, stream_, H, own);
     if (halo_fn_) {  // the neighbours' planes arrive in the halo planes of the leg's input
       if (halo_drain_) be::stream_sync(stream_);
       halo_fn_(halo_user_, work_, view, i);
     }
     ensure_work2();
     const cfloat* in = (const cfloat*)work_;
+    const cfloat* in_n = packed_ ? nullptr : work_nyq_;
     cfloat* out = (cfloat*)work2_;
+    cfloat* out_n = packed_ ? nullptr : work2_nyq_;
     if (H == 0) {
       if (halo_fn_ && halo_split_) {  // (no ranges, e.g. rows that do not end on tile boundaries: one part)
         if (halo_drain_) be::stream_sync(stream_);
         halo_fn_(halo_user_, work_, view, i + 4);
       }
-      dim0_conv(s, i, in, nullptr, out, nullptr, prof, stream_);
+      dim0_conv(s, i, in, in_n, out, out_n, prof, stream_);
     } else if (halo_split_ && own > 2 * H) {
-      dim0_conv(s, i, in, nullptr, out, nullptr, prof, stream_, 2 * H, own - 2 * H, true);
+      dim0_conv(s, i, in, in_n, out, out_n, prof, stream_, 2 * H, own - 2 * H, true);
       if (halo_drain_) be::stream_sync(stream_);
       halo_fn_(halo_user_, work_, view, i + 4);  // the halo planes must be in place behind this call
-      dim0_conv(s, i, in, nullptr, out, nullptr, nullptr, stream_, H, H, false);
-      dim0_conv(s, i, in, nullptr, out, nullptr, nullptr, stream_, own, H, false);
+      dim0_conv(s, i, in, in_n, out, out_n, nullptr, stream_, H, H, false);
+      dim0_conv(s, i, in, in_n, out, out_n, nullptr, stream_, own, H, false);
     } else {
       if (halo_split_) {
         if (halo_drain_) be::stream_sync(stream_);
         halo_fn_(halo_user_, work_, view, i + 4);
       }
-      dim0_conv(s, i, in, nullptr, out, nullptr, prof, stream_, H, own, true);
+      dim0_conv(s, i, in, in_n, out, out_n, prof, stream_, H, own, true);
     }
     std::swap(work_, work2_);
     std::swap(work_nyq_, work2_nyq_);
-    P.axis1(MVN_ST_INV, (cfloat*)work_, nullptr, stream_, prof, stream_, H, own);
+    P.axis1(MVN_ST_INV, (cfloat*)work_, wn(), stream_, prof, stream_, H, own);
     if (halo_fn_ && halo_post_) {  // the slabs merge their reports of non-finite inputs under the dim1 pass
       if (halo_drain_) be::stream_sync(stream_);
       halo_fn_(halo_user_, work_, view, i + 2);
@@ -1075,7 +1085,8 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
     return;
   }
   if (halo_fn_)
-    throw std::logic_error("mvn: halo mode needs every PSF in the direct form (<= 33 planes) and the packed Nyquist layout");
+    throw std::logic_error("mvn: halo mode needs every PSF in the direct form (<= 33 planes) and Nyquist bins that need no "
+                           "launches of their own (packed, or riding in the fixed-length dim1 kernels)");
   if (!s.tap_k[i]) {
     P.middle_passes((cfloat*)work_, work_nyq_, (const cfloat*)(i == 0 ? s.spec1 : s.spec2), i == 0 ? s.nyq1 : s.nyq2,
                     stream_, prof, side, spec_tiled_);
@@ -1399,8 +1410,9 @@ void Engine::set_halo_hook(halo_fn_t fn, void* user, bool drain, bool post) {
   if (fn) {
     if (!plan_->L.even || !mvn_dim0_packed_possible(plan_->L.d0))
       throw std::invalid_argument("mvn: halo mode needs an even last extent and at most 4062 planes per rank");
-    packed_allowed_ = true;
+    packed_allowed_ = true;  // (a hook that also exchanges the Nyquist plane says so: set_halo_nyq_aware)
   }
+  halo_nyq_aware_ = false;
   halo_fn_ = fn;
   halo_user_ = user;
   halo_drain_ = drain;

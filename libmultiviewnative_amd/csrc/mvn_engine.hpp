@@ -291,6 +291,17 @@ class Engine {
   // once more in between, with conv + 4 - the halo planes need to be in place only behind THAT call, so that an
   // exchange started at the first call runs beside the first part.
   void set_halo_planes(int planes, bool split);
+  // The hook also fills the halo planes of the Nyquist plane (leg_input_nyq(), [d0][d1] complex) when the engine
+  // runs the split layout: the engine then need not pack the Nyquist bins into the DC column, which costs 6 % at
+  // 512^3 (profiles/r04_layouts.md).  layout: -1 the engine's own rule (packed up to 256 MB per volume), 0 split,
+  // 1 packed - slabs of one volume take the WHOLE volume's layout, so that they run its arithmetic.
+  void set_halo_nyq_aware(int layout) {
+    halo_nyq_aware_ = true;
+    layout_override_ = layout;
+    if (!plan_->nyq_rides()) layout_override_ = 1;  // (run-time-radix dim1 kernels carry no riders)
+  }
+  // input of the dim0 leg in flight: its Nyquist plane (nullptr in the packed layout); valid inside the hook
+  void* leg_input_nyq() const { return packed_ ? nullptr : (void*)work_nyq_; }
   // The poison word (mvn_dim0_direct.hpp, EpilogueParams::poison): a direct dim0 leg that met a non-finite input
   // stores its epoch there.  poison_ptr(): the device word; bind_poison(): use caller-owned device memory (4 bytes,
   // zeroed) instead, e.g. a torch tensor a collective can MAX-reduce in place; poison_get() drains the stream and
@@ -321,6 +332,8 @@ class Engine {
   bool would_be_direct(const int* kdims);
   // the direct dim0 leg is enabled and is the better leg for PSFs of this depth on a volume of these extents
   static bool direct_ok_for(int k0, int d0, int d1, int d2);
+  // does a volume of this size keep its Nyquist bins packed in the DC column (when every PSF is in the direct form)?
+  static bool packed_layout_for(size_t volume_bytes);
   void set_all_direct_hint(bool all) { packed_hint_ = all; }
   // a cached engine starts every ABI call from a clean per-call state
   void begin_call() {
@@ -373,7 +386,8 @@ class Engine {
   bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
   halo_fn_t halo_fn_ = nullptr;
   void* halo_user_ = nullptr;
-  bool halo_drain_ = true, halo_post_ = false, halo_split_ = false;
+  bool halo_drain_ = true, halo_post_ = false, halo_split_ = false, halo_nyq_aware_ = false;
+  int layout_override_ = -1;
   int halo_planes_ = 0;
   bool halo_ranged() const;
   unsigned* poison_ = nullptr;      // the word in use: poison_own_, or caller-owned memory (bind_poison)

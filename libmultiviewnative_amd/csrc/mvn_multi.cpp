@@ -102,6 +102,9 @@ HaloGroup::HaloGroup(const std::vector<int>& devices, const shape_t& ext, int h,
     s.halo_stream = be::stream_create();
     s.eng->set_halo_hook(&HaloGroup::hook, &s, /*drain=*/false, /*post=*/true);
     s.eng->set_halo_planes(h, /*split=*/true);
+    // the slabs run the layout the WHOLE volume would have on one device (packed Nyquist bins up to 256 MB): the
+    // same arithmetic as the one-device call, whatever the slab size
+    s.eng->set_halo_nyq_aware(Engine::packed_layout_for(Layout(ext[0], ext[1], ext[2]).real_floats() * sizeof(float)) ? 1 : 0);
   }
   // a leg that meets a non-finite input tells every slab (Dim0DirectParams::poison_peers)
   for (int a = 0; a < P; ++a)
@@ -166,6 +169,7 @@ void HaloGroup::before_leg(Slab& s, void* spectrum) {
   const int P = (int)slabs_.size();
   const int par = (int)(s.convs & 1);
   s.spectrum = spectrum;
+  s.spectrum_nyq = s.eng->leg_input_nyq();  // (split layout: the Nyquist plane has halo planes of its own)
   be::event_record(s.e_fwd[par], s.eng->stream());
   barrier_.wait();
   Slab& lo = slabs_[(size_t)((s.index + P - 1) % P)];
@@ -182,6 +186,13 @@ void HaloGroup::before_leg(Slab& s, void* spectrum) {
   // planes [nz + h, nz + 2 h) <- the upper neighbour's first h own planes [h, 2 h)
   be::copy_peer(mine + (size_t)(s.nz + h_) * pb, s.dev, static_cast<const char*>(up.spectrum) + (size_t)h_ * pb, up.dev,
                 (size_t)h_ * pb, hs);
+  if (s.spectrum_nyq) {
+    const size_t nb = (size_t)L.d1 * sizeof(cfloat);  // one plane of the Nyquist plane: a line of d1 bins
+    char* mn = static_cast<char*>(s.spectrum_nyq);
+    be::copy_peer(mn, s.dev, static_cast<const char*>(lo.spectrum_nyq) + (size_t)lo.nz * nb, lo.dev, (size_t)h_ * nb, hs);
+    be::copy_peer(mn + (size_t)(s.nz + h_) * nb, s.dev, static_cast<const char*>(up.spectrum_nyq) + (size_t)h_ * nb,
+                  up.dev, (size_t)h_ * nb, hs);
+  }
   be::event_record(s.e_copy[par], hs);
 }
 

@@ -98,6 +98,7 @@ class HaloGroup {
     be::event_t e_leg[2] = {nullptr, nullptr};   // my leg (and the dim1 pass behind it) is done
     be::stream_t halo_stream = nullptr;          // the peer copies run here, beside the interior part of the leg
     void* spectrum = nullptr;                    // input of the leg in flight (the engine's work volume)
+    void* spectrum_nyq = nullptr;                // ... and its Nyquist plane (split layout), nullptr when packed
     unsigned long convs = 0;
     int host_a = 0, host_b = 0, embed_z = 0;     // planes [host_a, host_b) of the host stacks, at plane embed_z of the engine
   };

@@ -191,10 +191,12 @@ class HaloSlabDriver:
     """
 
     def __init__(self, binding, full_shape, num_views, max_psf_depth, dist=None, rank=0, world=1, device=0,
-                 torch_device=None):
+                 torch_device=None, force_collective=False):
         import torch
         self.torch = torch
-        self.dist = dist if world > 1 else None
+        # force_collective: one rank that still exchanges through isend / irecv with itself and reduces its poison
+        # word - a rehearsal of the multi-rank code path (device tensors, stream ordering) on a one-GPU box
+        self.dist = dist if (world > 1 or (force_collective and dist is not None)) else None
         self.rank, self.world = rank, world
         d0, d1, d2 = (int(x) for x in full_shape)
         if d0 % world:

@@ -1132,3 +1132,36 @@ def test_resident_group_of_slab_engines(emu, monkeypatch):
         g.close()
     with pytest.raises(native.MvnError):  # more halo planes than planes per slab
         emu.group([0, 0, 0, 0], (16, 16, 32), 5, V)
+
+
+def test_slabs_of_a_large_volume_keep_the_split_nyquist_layout(emu, monkeypatch):
+    # Above 256 MB a volume keeps its Nyquist plane (the packed DC column costs 6 % at 512^3), the plane's dim1 lines
+    # ride in the main dim1 launches, and the slabs of MVN_DEVICES run that same layout whatever their own size:
+    # the Nyquist plane has halo planes of its own, exchanged with the main array's.  Forced here on a small volume
+    # (MVN_NYQ_PACKED=0) with fixed-length dim1 kernels (d1 = 64): bit-equal to one engine, and to the oracle's
+    # flood through an Inf voxel.
+    monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_ITEMS", raising=False)
+    monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_PLANE", raising=False)
+    monkeypatch.setenv("MVN_NYQ_PACKED", "0")
+    shape, V, ks = (48, 64, 64), 2, (7, 5, 3)
+    assert emu.plan_describe(shape)["fx_ax1"] == 1
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks, seed=25)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    emu.l.mvn_release_cached_engines()
+    try:
+        single = emu.gpu_deconvolve(psi0, h)
+        for devices in ("0,0", "0,0,0"):
+            monkeypatch.setenv("MVN_DEVICES", devices)
+            before = emu.l.mvn_multi_device_calls()
+            multi = emu.gpu_deconvolve(psi0, h)
+            assert emu.l.mvn_multi_device_calls() == before + 1
+            assert np.array_equal(multi, single), devices
+            bad = psi0.copy()
+            bad[5, 5, 5] = np.inf
+            assert np.array_equal(emu.gpu_deconvolve(bad, h), orc.cpu_deconvolve(bad, h, 4), equal_nan=True)
+            monkeypatch.delenv("MVN_DEVICES")
+        ref = orc.cpu_deconvolve(psi0, h, 4)
+        assert np.abs(single - ref).max() <= 1e-5 * np.abs(ref).max()
+    finally:
+        monkeypatch.delenv("MVN_DEVICES", raising=False)
+        emu.l.mvn_release_cached_engines()

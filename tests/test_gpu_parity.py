@@ -1192,6 +1192,39 @@ def test_mvn_devices_runs_the_abi_call_as_halo_slabs(gpu, orc, monkeypatch, devi
         gpu.check(gpu.l.mvn_release_cached_engines())
 
 
+def test_slabs_of_a_large_volume_keep_the_split_nyquist_layout(gpu, orc, monkeypatch):
+    # Above 256 MB a volume keeps its Nyquist plane, whose dim1 lines ride in the main dim1 launches; the slabs of
+    # MVN_DEVICES run that layout whatever their own size and exchange the plane's halo planes too.  Forced on small
+    # volumes (MVN_NYQ_PACKED=0), d1 = 64 / 512 (fixed-length dim1 kernels with riders), d2 = 128 / 512 (tiled and
+    # wave-row last-axis kernels): bit-equal to one engine, the oracle's flood through an Inf voxel.
+    monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_ITEMS", raising=False)
+    monkeypatch.delenv("MVN_DIM0_DIRECT_MIN_PLANE", raising=False)
+    monkeypatch.setenv("MVN_NYQ_PACKED", "0")
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    try:
+        for shape, V, ks in (((48, 64, 128), 2, (7, 5, 3)), ((96, 512, 512), 1, (15, 5, 5))):
+            _, views, k1, k2, w, psi0 = realistic_views(shape, V, ks, seed=25)
+            h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+            monkeypatch.delenv("MVN_DEVICES", raising=False)
+            single = gpu.gpu_deconvolve(psi0, h)
+            ref = orc.cpu_deconvolve(psi0, h, 8)
+            mx, rms = rel_err(single, ref)
+            assert mx <= MAX_REL and rms <= RMS_REL, (shape, mx, rms)
+            for devices in ("0,0", "0,0,0"):
+                monkeypatch.setenv("MVN_DEVICES", devices)
+                before = gpu.l.mvn_multi_device_calls()
+                multi = gpu.gpu_deconvolve(psi0, h)
+                assert gpu.l.mvn_multi_device_calls() == before + 1
+                assert np.array_equal(multi, single), (shape, devices)
+            if shape[0] == 48:
+                bad = psi0.copy()
+                bad[5, 5, 5] = np.inf
+                assert np.array_equal(gpu.gpu_deconvolve(bad, h), orc.cpu_deconvolve(bad, h, 4), equal_nan=True)
+    finally:
+        monkeypatch.delenv("MVN_DEVICES", raising=False)
+        gpu.check(gpu.l.mvn_release_cached_engines())
+
+
 def test_psf_cache_invalidation_on_gpu(gpu, orc):
     # SURVEY.md 8f row 3 on the device: block-after-block calls re-use the resident PSF spectra; the
     # same shape with changed kernel bytes must prepare them again and give the oracle's result

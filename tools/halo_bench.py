@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--all-ranks-on-device", type=int, default=-1)
     ap.add_argument("--ranks", type=int, default=0, help="spawn this many ranks from here (no torchrun)")
     ap.add_argument("--dump-psi", default=None)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one rank that still exchanges through torch.distributed with itself (isend / irecv of device "
+                         "tensors over RCCL, poison word all-reduced): rehearses the multi-rank path on a one-GPU box")
     args = ap.parse_args()
 
     if args.ranks > 1 and "RANK" not in os.environ:
@@ -46,6 +49,10 @@ def main():
 
     os.environ.setdefault("MVN_DIM0_DIRECT_MIN_ITEMS", "0")  # the mode is built on the direct dim0 leg
     os.environ["MVN_DIM0_DIRECT_MIN_ITEMS"] = "0"
+    if args.force_dist and "RANK" not in os.environ:
+        import bench
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(bench.free_port()))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,7 +61,7 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -67,8 +74,8 @@ def main():
     lib = native.lib()  # raises if the HIP library is missing: there is no fallback
     shape, V = tuple(args.size), args.views
     tdev = torch.device("cuda", local_rank) if (world == 1 or args.backend == "nccl") else torch.device("cpu")
-    drv = HaloSlabDriver(lib, shape, V, min(args.psf, shape[0]), dist=dist if world > 1 else None, rank=rank,
-                         world=world, device=local_rank, torch_device=tdev)
+    drv = HaloSlabDriver(lib, shape, V, min(args.psf, shape[0]), dist=dist if (world > 1 or args.force_dist) else None,
+                         rank=rank, world=world, device=local_rank, torch_device=tdev, force_collective=args.force_dist)
     sl = slice(drv.z0, drv.z0 + drv.nz)
     weights = np.full((drv.nz,) + shape[1:], 1.0 / V, np.float32)
     for v in range(V):
@@ -113,7 +120,7 @@ def main():
                                       "halo exchange before every dim0 leg (backend %s)" % (drv.nz, drv.h, args.backend)},
             "psi_finite_positive": bool(np.isfinite(psi).all() and (psi > 0).all())}), flush=True)
     drv.close()
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

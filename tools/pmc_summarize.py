@@ -32,13 +32,20 @@ KINDS = {
 
 
 def read(dirname, counter):
-    tot, cnt = collections.Counter(), collections.Counter()
+    """per kernel name: sum and count of the counter over its launches with the LARGEST grid (the same kernels also
+    prepare the PSFs, on arrays of a few planes: those launches are not the passes of the loop)"""
+    rows = []
     for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] != counter:
-                continue
-            name = row["Kernel_Name"]
-            tot[name] += float(row["Counter_Value"])
+            if row["Counter_Name"] == counter:
+                rows.append((row["Kernel_Name"], int(row.get("Grid_Size") or 0), float(row["Counter_Value"])))
+    largest = collections.Counter()
+    for name, grid, _ in rows:
+        largest[name] = max(largest[name], grid)
+    tot, cnt = collections.Counter(), collections.Counter()
+    for name, grid, value in rows:
+        if grid == largest[name]:
+            tot[name] += value
             cnt[name] += 1
     return tot, cnt
 

@@ -120,6 +120,17 @@ MVN_HD void mvn_cmac2(cfloat& s1, cfloat& s2, cfloat a, cfloat w) {
 #endif
 }
 
+// the first tap of a pair of chains: products instead of multiply-adds onto a zeroed register pair
+MVN_HD void mvn_cmul2(cfloat& s1, cfloat& s2, cfloat a, cfloat w) {
+#if defined(MVN_PACKED)
+  MVN_PK2(s1, "v_pk_mul_f32", a, w, "op_sel_hi:[0,1]");
+  MVN_PK2(s2, "v_pk_mul_f32", a, w, "op_sel:[1,0] op_sel_hi:[1,1]");
+#else
+  s1 = cmake(a.x * w.x, a.x * w.y);
+  s2 = cmake(a.y * w.x, a.y * w.y);
+#endif
+}
+
 // Non-finite values.  The RL loop lets NaN / Inf flow (0 / 0 and x / 0 quotients, inc/cpu_kernels.h:19-26)
 // and an FFT-based convolution turns ONE such voxel into a volume of NaN (inc/cpu_convolve.h:256-268), which
 // the update then clamps to minValue everywhere (inc/cpu_kernels.h:40-47,76-83) - the reference's, and the
@@ -301,16 +312,26 @@ struct Dim0Walk {
   unsigned bytes;      // of a plane
   int z, znew, d0;
 };
+// (the wraps happen twice per walk: kept as rarely taken BRANCHES - the empty inline statement stops the compiler
+// from turning them into four selects per pointer and step, on the critical path of a wave that has only one or
+// two others to hide behind)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MVN_HOST_EMU)
+#define MVN_D0_KEEP_BRANCH() asm volatile("")
+#else
+#define MVN_D0_KEEP_BRANCH() (void)0
+#endif
 MVN_HD void mvn_dim0_advance(Dim0Walk& w) {
   ++w.znew;
   w.pin += w.plane;
-  if (w.znew == w.d0) {
+  if (__builtin_expect(w.znew == w.d0, 0)) {
+    MVN_D0_KEEP_BRANCH();
     w.znew = 0;
     w.pin = w.in0;
   }
   ++w.z;
   w.pout += w.plane;
-  if (w.z == w.d0) {
+  if (__builtin_expect(w.z == w.d0, 0)) {
+    MVN_D0_KEEP_BRANCH();
     w.z = 0;
     w.pout = w.out0;
   }
@@ -358,26 +379,32 @@ template <int K, int PF, int U>
 MVN_HD void mvn_dim0_step(Dim0Window<K, PF>& r, Dim0Walk& w, unsigned b, int nout, int nn) {
   constexpr int KW = K + PF;
   if (nn + U >= nout) return;  // nout outputs in all, the walk is cyclic
-  cfloat s1 = cmake(0.f, 0.f), s2 = cmake(0.f, 0.f);
+  cfloat s1, s2;
 #if defined(MVN_EXPERIMENTS) && defined(MVN_D0_EXP_TAPS)
+  s1 = s2 = cmake(0.f, 0.f);
   // timing experiment (variant builds only, WRONG results): the walk with only the first few multiply-adds
 #pragma unroll
   for (int j = 0; j < (K < MVN_D0_EXP_TAPS ? K : MVN_D0_EXP_TAPS); ++j) mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
 #elif MVN_D0_CHAINS == 2
   // even and odd taps in chains of their own: four instructions between a multiply-add and the next one of its
   // chain - the compiler asks for two between inline instructions and fills what is missing with wait states
-  cfloat t1 = cmake(0.f, 0.f), t2 = cmake(0.f, 0.f);
+  mvn_cmul2(s1, s2, r.w[(PF - U + KW) % KW], r.tap[0]);
+  if constexpr (K > 1) {
+    cfloat t1, t2;
+    mvn_cmul2(t1, t2, r.w[(1 + PF - U + KW) % KW], r.tap[1]);
 #pragma unroll
-  for (int j = 0; j + 1 < K; j += 2) {
-    mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
-    mvn_cmac2(t1, t2, r.w[(j + 1 + PF - U + KW) % KW], r.tap[j + 1]);
+    for (int j = 2; j + 1 < K; j += 2) {
+      mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
+      mvn_cmac2(t1, t2, r.w[(j + 1 + PF - U + KW) % KW], r.tap[j + 1]);
+    }
+    if (K % 2) mvn_cmac2(s1, s2, r.w[(K - 1 + PF - U + KW) % KW], r.tap[K - 1]);
+    s1 = cadd(s1, t1);
+    s2 = cadd(s2, t2);
   }
-  if (K % 2) mvn_cmac2(s1, s2, r.w[(K - 1 + PF - U + KW) % KW], r.tap[K - 1]);
-  s1 = cadd(s1, t1);
-  s2 = cadd(s2, t2);
 #else
+  mvn_cmul2(s1, s2, r.w[(PF - U + KW) % KW], r.tap[0]);
 #pragma unroll
-  for (int j = 0; j < K; ++j) mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
+  for (int j = 1; j < K; ++j) mvn_cmac2(s1, s2, r.w[(j + PF - U + KW) % KW], r.tap[j]);
 #endif
   mvn_dim0_st(w.pout, b, w.bytes, cadd_i<+1>(s1, s2));  // (s1.x - s2.y, s1.y + s2.x)
   // x_0 = in[z + h] runs over every plane of the column once: tracked HERE, where it has long arrived

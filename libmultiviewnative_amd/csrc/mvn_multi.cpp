@@ -96,10 +96,11 @@ HaloGroup::HaloGroup(const std::vector<int>& devices, const shape_t& ext, int h,
     s.eng.reset(new Engine(s.dev, shape, V));
     for (int i = 0; i < 2; ++i) {
       s.e_fwd[i] = be::event_create_sync();
-      s.e_copy[i] = be::event_create_sync();
+      s.e_copy[i][0] = be::event_create_sync();
+      s.e_copy[i][1] = be::event_create_sync();
       s.e_leg[i] = be::event_create_sync();
+      s.halo_stream[i] = be::stream_create();
     }
-    s.halo_stream = be::stream_create();
     s.eng->set_halo_hook(&HaloGroup::hook, &s, /*drain=*/false, /*post=*/true);
     s.eng->set_halo_planes(h, /*split=*/true);
     // the slabs run the layout the WHOLE volume would have on one device (packed Nyquist bins up to 256 MB): the
@@ -128,14 +129,15 @@ HaloGroup::~HaloGroup() {
     } catch (...) {
     }
     s.eng.reset();
-    try {
-      if (s.halo_stream) be::stream_sync(s.halo_stream);
-    } catch (...) {
-    }
-    be::stream_destroy(s.halo_stream);
     for (int i = 0; i < 2; ++i) {
+      try {
+        if (s.halo_stream[i]) be::stream_sync(s.halo_stream[i]);
+      } catch (...) {
+      }
+      be::stream_destroy(s.halo_stream[i]);
       be::event_destroy(s.e_fwd[i]);
-      be::event_destroy(s.e_copy[i]);
+      be::event_destroy(s.e_copy[i][0]);
+      be::event_destroy(s.e_copy[i][1]);
       be::event_destroy(s.e_leg[i]);
     }
   }
@@ -174,26 +176,27 @@ void HaloGroup::before_leg(Slab& s, void* spectrum) {
   barrier_.wait();
   Slab& lo = slabs_[(size_t)((s.index + P - 1) % P)];
   Slab& up = slabs_[(size_t)((s.index + 1) % P)];
-  be::stream_t hs = s.halo_stream;
-  be::stream_wait_event(hs, s.e_fwd[par]);  // (my halo planes are free: every earlier reader is behind this event)
-  be::stream_wait_event(hs, lo.e_fwd[par]);
-  if (&up != &lo) be::stream_wait_event(hs, up.e_fwd[par]);
   const Layout& L = s.eng->layout();
   const size_t pb = (size_t)L.d1 * (size_t)L.C * sizeof(cfloat);  // one plane of the spectrum
+  const size_t nb = (size_t)L.d1 * sizeof(cfloat);                // one plane of the Nyquist plane: a line of d1 bins
   char* mine = static_cast<char*>(spectrum);
-  // planes [0, h) <- the lower neighbour's last h own planes [nz, nz + h) of its extended slab
-  be::copy_peer(mine, s.dev, static_cast<const char*>(lo.spectrum) + (size_t)lo.nz * pb, lo.dev, (size_t)h_ * pb, hs);
-  // planes [nz + h, nz + 2 h) <- the upper neighbour's first h own planes [h, 2 h)
-  be::copy_peer(mine + (size_t)(s.nz + h_) * pb, s.dev, static_cast<const char*>(up.spectrum) + (size_t)h_ * pb, up.dev,
-                (size_t)h_ * pb, hs);
-  if (s.spectrum_nyq) {
-    const size_t nb = (size_t)L.d1 * sizeof(cfloat);  // one plane of the Nyquist plane: a line of d1 bins
-    char* mn = static_cast<char*>(s.spectrum_nyq);
-    be::copy_peer(mn, s.dev, static_cast<const char*>(lo.spectrum_nyq) + (size_t)lo.nz * nb, lo.dev, (size_t)h_ * nb, hs);
-    be::copy_peer(mn + (size_t)(s.nz + h_) * nb, s.dev, static_cast<const char*>(up.spectrum_nyq) + (size_t)h_ * nb,
-                  up.dev, (size_t)h_ * nb, hs);
+  char* mine_n = static_cast<char*>(s.spectrum_nyq);
+  // one halo stream per side: the two neighbours sit behind two different links, their planes travel side by side
+  for (int side = 0; side < 2; ++side) {
+    Slab& nb_slab = side == 0 ? lo : up;
+    be::stream_t hs = s.halo_stream[side];
+    be::stream_wait_event(hs, s.e_fwd[par]);  // (my halo planes are free: every earlier reader is behind this event)
+    be::stream_wait_event(hs, nb_slab.e_fwd[par]);
+    // side 0: planes [0, h) <- the lower neighbour's last h own planes [nz, nz + h) of its extended slab
+    // side 1: planes [nz + h, nz + 2 h) <- the upper neighbour's first h own planes [h, 2 h)
+    const size_t dst = side == 0 ? 0 : (size_t)(s.nz + h_), src = side == 0 ? (size_t)nb_slab.nz : (size_t)h_;
+    be::copy_peer(mine + dst * pb, s.dev, static_cast<const char*>(nb_slab.spectrum) + src * pb, nb_slab.dev,
+                  (size_t)h_ * pb, hs);
+    if (mine_n)
+      be::copy_peer(mine_n + dst * nb, s.dev, static_cast<const char*>(nb_slab.spectrum_nyq) + src * nb, nb_slab.dev,
+                    (size_t)h_ * nb, hs);
+    be::event_record(s.e_copy[par][side], hs);
   }
-  be::event_record(s.e_copy[par], hs);
 }
 
 // In front of the part of the leg that reads the halo planes - and WRITES, in the engine's other work volume, the
@@ -204,12 +207,13 @@ void HaloGroup::before_boundary(Slab& s) {
   const int P = (int)slabs_.size();
   const int par = (int)(s.convs & 1);
   be::stream_t st = s.eng->stream();
-  be::stream_wait_event(st, s.e_copy[par]);
+  be::stream_wait_event(st, s.e_copy[par][0]);
+  be::stream_wait_event(st, s.e_copy[par][1]);
   if (s.convs > 0) {
     Slab& lo = slabs_[(size_t)((s.index + P - 1) % P)];
     Slab& up = slabs_[(size_t)((s.index + 1) % P)];
-    be::stream_wait_event(st, lo.e_copy[par ^ 1]);
-    if (&up != &lo) be::stream_wait_event(st, up.e_copy[par ^ 1]);
+    be::stream_wait_event(st, lo.e_copy[par ^ 1][1]);  // the lower neighbour's UPPER halo came from my first own planes
+    be::stream_wait_event(st, up.e_copy[par ^ 1][0]);  // the upper neighbour's LOWER halo from my last
   }
 }
 
@@ -250,7 +254,8 @@ void HaloGroup::on_every_slab(const std::function<void(Slab&)>& body) {
     try {
       be::set_device(slabs_[(size_t)r].dev);
       slabs_[(size_t)r].eng->sync();
-      be::stream_sync(slabs_[(size_t)r].halo_stream);
+      be::stream_sync(slabs_[(size_t)r].halo_stream[0]);
+      be::stream_sync(slabs_[(size_t)r].halo_stream[1]);
     } catch (...) {
     }
   }

@@ -94,9 +94,11 @@ class HaloGroup {
     int z0 = 0, nz = 0;  // planes [z0, z0 + nz) of the volume; the engine holds nz + 2 h planes
     std::unique_ptr<Engine> eng;
     be::event_t e_fwd[2] = {nullptr, nullptr};   // my dim1 pass before a leg is done (parity of the convolution count)
-    be::event_t e_copy[2] = {nullptr, nullptr};  // my halo planes have arrived = the neighbours' planes have been read
+    // my lower [.][0] / upper [.][1] halo planes have arrived = that neighbour's planes have been read
+    be::event_t e_copy[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     be::event_t e_leg[2] = {nullptr, nullptr};   // my leg (and the dim1 pass behind it) is done
-    be::stream_t halo_stream = nullptr;          // the peer copies run here, beside the interior part of the leg
+    // the peer copies run here, beside the interior part of the leg: one stream per side (two neighbours, two links)
+    be::stream_t halo_stream[2] = {nullptr, nullptr};
     void* spectrum = nullptr;                    // input of the leg in flight (the engine's work volume)
     void* spectrum_nyq = nullptr;                // ... and its Nyquist plane (split layout), nullptr when packed
     unsigned long convs = 0;

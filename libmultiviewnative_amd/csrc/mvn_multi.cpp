@@ -182,9 +182,10 @@ void HaloGroup::before_leg(Slab& s, void* spectrum) {
   char* mine = static_cast<char*>(spectrum);
   char* mine_n = static_cast<char*>(s.spectrum_nyq);
   // one halo stream per side: the two neighbours sit behind two different links, their planes travel side by side
+  // (two slabs: the one neighbour is both, one link, one stream - a process's streams share 4 hardware queues)
   for (int side = 0; side < 2; ++side) {
     Slab& nb_slab = side == 0 ? lo : up;
-    be::stream_t hs = s.halo_stream[side];
+    be::stream_t hs = s.halo_stream[&lo == &up ? 0 : side];
     be::stream_wait_event(hs, s.e_fwd[par]);  // (my halo planes are free: every earlier reader is behind this event)
     be::stream_wait_event(hs, nb_slab.e_fwd[par]);
     // side 0: planes [0, h) <- the lower neighbour's last h own planes [nz, nz + h) of its extended slab

@@ -790,9 +790,17 @@ MVN_HD void fx_fused_lds_body(const StridedParams& P, long block, cfloat* lds, C
 // Long lines (N > 1024): a 16-column tile (128-byte row segments) is twice what the LDS holds.
 // After stage 0 (radix 8, in registers) a line is 8 independent sub-lines of M0 = N/8 rows, so the
 // whole tile is kept in REGISTERS (8 * IT0 16-byte values per thread) and the inner stages run on
-// half of it at a time: sub-lines 0-3, then 4-7, each through a window of W = N/2 LDS rows.
-//   [window r: loads + last stage -> LDS, inner stages, LDS -> registers] x 2 -> stage 0 -> stores
+// a part of it at a time: NWIN windows of 8 / NWIN sub-lines, each through W = N / NWIN LDS rows.
+//   [window r: loads + last stage -> LDS, inner stages, LDS -> registers] x NWIN -> stage 0 -> stores
 // The 8-column form (64-byte segments, FxStridedCfg) ran these passes at 3.0-3.4 TB/s.
+// Round 4: the windows are a parameter (MVN_FX_SPLIT_NWIN_LONG = 2 or 4 for N >= 1536).  With half-line windows the
+// rows a thread holds between their loads and the last stage (r.pf) are 80 registers and the NEXT tile's first
+// window cannot be requested before the finished tile's stores (256 VGPRs + scratch, round 3); the counters show the
+// pass short of requests in flight (11.7 k device-wide against 20 k at 512^3, profiles/r04_mem_counters_1920.md).
+// With QUARTER windows (40 registers) the next tile's first window is requested under the last window's stages and
+// the stores, 237 - 247 VGPRs, no scratch - and the pass takes exactly as long (64 x 1920 x 1920, same box:
+// forward 0.436 / 0.434 ms, inverse 0.396 / 0.396, profiles/r04_ab_split_windows_1920.txt): those loads were not what
+// it waits for.  Half windows stay the default (fewer barriers).
 // ---------------------------------------------------------------------------------------------
 template <int N>
 struct FxSplitCfg {
@@ -801,7 +809,14 @@ struct FxSplitCfg {
   static constexpr int NS = fx_nstages(N);
   static constexpr int M0 = fx_M(N, 0);
   static constexpr int RL = fx_radix(N, NS - 1);
-  static constexpr int W = N / 2;  // rows per window = 4 sub-lines
+#ifndef MVN_FX_SPLIT_NWIN_LONG
+#define MVN_FX_SPLIT_NWIN_LONG 2
+#endif
+  static constexpr int NWIN = N >= 1536 ? MVN_FX_SPLIT_NWIN_LONG : 2;  // windows per tile
+  static constexpr int SUB = 8 / NWIN;                               // sub-lines per window
+  static constexpr int W = N / NWIN;                                 // rows per window
+  // the next tile's first window is requested under the last window's stages and the stores (quarter windows)
+  static constexpr bool NEXT_AHEAD = NWIN > 2;
   static constexpr int NT1 = M0 * CH;
   // threads: 1280 runs best with 640 (two stage-0 items per thread; 320: +7 %), 1920 with 384 (five items; 640
   // and 960 threads: +2 - 6 %) - profiles/r03_rows_lds.md
@@ -816,7 +831,7 @@ struct FxSplitCfg {
   // the 1920 kernel keeps 28 bytes of scratch and wins too: 2.91 -> 2.37 ms on 320 x 1920 x 1920
   static constexpr bool FWD_DEFAULT = true;
   static constexpr int lds_cfloats = W * TP + (fx_twsize(N) - TW1);
-  static_assert(!USE || (fx_radix(N, 0) == 8 && NS >= 3 && N % 128 == 0 && W % RL == 0), "split plan");
+  static_assert(!USE || (fx_radix(N, 0) == 8 && NS >= 3 && N % 128 == 0 && W % RL == 0 && 8 % NWIN == 0), "split plan");
   static_assert(!USE || (NT % 64 == 0 && NT * IT0 == NT1), "split workgroup size");
   static_assert(!USE || sizeof(cfloat) * lds_cfloats <= 160 * 1024, "window does not fit the LDS");
 };
@@ -883,7 +898,7 @@ MVN_HD void fx_sp_tables(const StridedParams& P, cfloat* twl, int tid) {
   fx_copy_table<C::NT>(twl, P.ax.tws + C::TW1, fx_twsize(N) - C::TW1, tid);
 }
 
-// LDS -> registers of window WIN (sub-lines 4 WIN .. 4 WIN + 3); WIN is a template parameter so
+// LDS -> registers of window WIN (sub-lines SUB WIN .. SUB WIN + SUB - 1); WIN is a template parameter so
 // that every register index is a compile-time constant
 template <int N, int WIN>
 MVN_HD void fx_sp_collect(const cfloat* buf, FxSplitRegs<N>& r, int tid) {
@@ -894,7 +909,7 @@ MVN_HD void fx_sp_collect(const cfloat* buf, FxSplitRegs<N>& r, int tid) {
     const int q = w % C::CH, j2 = w / C::CH;
     const qfloat* d = reinterpret_cast<const qfloat*>(buf) + j2 * C::TPQ + q;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) r.a[it * 8 + 4 * WIN + kk] = d[kk * C::M0 * C::TPQ];
+    for (int kk = 0; kk < C::SUB; ++kk) r.a[it * 8 + C::SUB * WIN + kk] = d[kk * C::M0 * C::TPQ];
   }
 }
 
@@ -994,6 +1009,32 @@ MVN_HD long fx_sp_base(const StridedParams& P, long block) {
   return (long)o * P.ostride + (long)t * FxSplitCfg<N>::T;
 }
 
+// The windows of a tile one after the other: last stage of window WIN (its rows are in r.pf) -> LDS, and in the same
+// phase the request for the rows that come next - window WIN + 1 of this tile, or (quarter windows) window 0 of the
+// workgroup's NEXT tile, which then fly during the inner stages, the collect, stage 0 and the stores.
+template <int N, int SIGN, bool PERM, int WIN, typename Ctx>
+struct FxSplitWindows {
+  static MVN_HD void run(const StridedParams& P, long base, long next_base, bool has_next, cfloat* buf,
+                         const cfloat* twl, Ctx& ctx) {
+    typedef FxSplitCfg<N> C;
+    constexpr int NT_ = C::NT, NS = C::NS;
+    (void)NT_;
+    if constexpr (WIN < C::NWIN) {
+      if constexpr (WIN + 1 < C::NWIN) {
+        MVN_PHASE(ctx, (fx_sp_last_to_lds<N, SIGN>(buf, r, tid), fx_sp_fetch<N, PERM, 0, C::ITL>(P, base, WIN + 1, r, tid)));
+      } else if constexpr (C::NEXT_AHEAD) {
+        MVN_PHASE(ctx, (fx_sp_last_to_lds<N, SIGN>(buf, r, tid),
+                        has_next ? fx_sp_fetch<N, PERM, 0, C::ITL>(P, next_base, 0, r, tid) : (void)0));
+      } else {
+        MVN_PHASE(ctx, (fx_sp_last_to_lds<N, SIGN>(buf, r, tid)));
+      }
+      FxStagesQWin<N, SIGN, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
+      MVN_PHASE(ctx, (fx_sp_collect<N, WIN>(buf, r, tid)));
+      FxSplitWindows<N, SIGN, PERM, WIN + 1, Ctx>::run(P, base, next_base, has_next, buf, twl, ctx);
+    }
+  }
+};
+
 // tiles first, first + step, ... < total (MODE is FWD or INV).  Both directions are decimation in
 // time -- the tile ACCUMULATES in registers window by window, so the registers fill up only at
 // the end (a decimation-in-frequency forward form, with every row live from the start, spilled
@@ -1004,7 +1045,7 @@ template <int N, int MODE, typename Ctx>
 MVN_HD void fx_strided_split_body(const StridedParams& P, long first, long total, long step,
                                   cfloat* lds, Ctx& ctx) {
   typedef FxSplitCfg<N> C;
-  constexpr int NT_ = C::NT, NS = C::NS;
+  constexpr int NT_ = C::NT;
   constexpr int SIGN = MODE == MVN_ST_FWD ? -1 : +1;
   constexpr bool PERM = MODE == MVN_ST_FWD;
   (void)NT_;
@@ -1012,16 +1053,18 @@ MVN_HD void fx_strided_split_body(const StridedParams& P, long first, long total
   cfloat* twl = lds + C::W * C::TP;
   if (first >= total) return;
   MVN_PHASE(ctx, (fx_sp_tables<N>(P, twl, tid)));
+  if constexpr (C::NEXT_AHEAD) {
+    MVN_PHASE_NOSYNC(ctx, (fx_sp_fetch<N, PERM, 0, C::ITL>(P, fx_sp_base<N>(P, first), 0, r, tid)));
+  }
   for (long block = first; block < total; block += step) {
     MVN_TILE_LOOP_TOP(ctx);
     const long base = fx_sp_base<N>(P, block);
-    MVN_PHASE_NOSYNC(ctx, (fx_sp_fetch<N, PERM, 0, C::ITL>(P, base, 0, r, tid)));
-    MVN_PHASE(ctx, (fx_sp_last_to_lds<N, SIGN>(buf, r, tid), fx_sp_fetch<N, PERM, 0, C::ITL>(P, base, 1, r, tid)));
-    FxStagesQWin<N, SIGN, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
-    MVN_PHASE(ctx, (fx_sp_collect<N, 0>(buf, r, tid)));
-    MVN_PHASE(ctx, (fx_sp_last_to_lds<N, SIGN>(buf, r, tid)));
-    FxStagesQWin<N, SIGN, false, NS - 2, 1, Ctx>::run(buf, twl, ctx);
-    MVN_PHASE(ctx, (fx_sp_collect<N, 1>(buf, r, tid)));
+    if constexpr (!C::NEXT_AHEAD) {
+      MVN_PHASE_NOSYNC(ctx, (fx_sp_fetch<N, PERM, 0, C::ITL>(P, base, 0, r, tid)));
+    }
+    const bool has_next = block + step < total;
+    const long next_base = has_next ? fx_sp_base<N>(P, block + step) : base;
+    FxSplitWindows<N, SIGN, PERM, 0, Ctx>::run(P, base, next_base, has_next, buf, twl, ctx);
     MVN_PHASE_NOSYNC(ctx, (fx_sp_stage0_store<N, SIGN, PERM>(P, base, twl, r, tid)));
   }
 }

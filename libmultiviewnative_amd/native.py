@@ -53,6 +53,30 @@ def _dims(shape):
     return (C.c_int * 3)(*[int(s) for s in shape])
 
 
+class _Missing:
+    """A symbol an OLDER build of the library does not have (same-box A/B runs of a previous round's build through
+    MVN_PRODUCT_SO): prototypes can be set, a call fails loudly."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __call__(self, *a):
+        raise MvnError("this build of the library has no %s" % self.name)
+
+
+class _Tolerant:
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._cdll, name)
+        except AttributeError:
+            m = _Missing(name)
+            object.__setattr__(self, name, m)
+            return m
+
+
 class Binding:
     def __init__(self, path):
         if not os.path.exists(path):
@@ -61,6 +85,8 @@ class Binding:
                 "__graft_entry__ as g; g.build()'` (there is no CPU fallback)" % path)
         self.path = path
         self.l = C.CDLL(path)
+        if os.environ.get("MVN_PRODUCT_SO") and os.path.abspath(path) == os.path.abspath(os.environ["MVN_PRODUCT_SO"]):
+            self.l = _Tolerant(self.l)  # an A/B build named explicitly may be an older one; the product itself is strict
         l = self.l
         i3 = C.POINTER(C.c_int)
         l.mvn_last_error.restype = C.c_char_p

@@ -13,5 +13,5 @@ for v in - "$@" -; do
   MVN_PRODUCT_SO=$PWD/$so timeout -k 10 300 python bench.py $ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('  %.3f ms/step  %.2f it/s ' % (d['ms_per_step'], d['value']), {k: round(v['avg_ms'], 4) for k, v in d['roofline']['per_kernel'].items()})"
+print('  %.3f ms/step  %.2f it/s ' % (d['ms_per_step'], d['value']), {k: round(v['avg_ms'], 4) for k, v in ((d.get('roofline') or {}).get('per_kernel') or {}).items()})"
 done

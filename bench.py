@@ -332,7 +332,21 @@ def main():
     ap.add_argument("--check-parity", action="store_true",
                     help="N > 1: rank 0 still runs the one-view parity check / CPU sample (default: N = 1 only)")
     ap.add_argument("--dump-psi", default=None, help="rank 0 saves the final psi here (.npy)")
+    ap.add_argument("--exact-halo-child", default=None, metavar="DEVICES",
+                    help="internal: run only the exact_halo_mode measurement on these devices (comma separated) and "
+                         "print its JSON block (the N > 1 lines start it as a child process with a time limit)")
     args = ap.parse_args()
+    if args.exact_halo_child:
+        cfg = CONFIGS[args.config]
+        shape = tuple(args.size or cfg["size"])
+        V = args.views if args.views is not None else cfg["views"]
+        with stdout_to_stderr():
+            from libmultiviewnative_amd import native
+            devices = [int(d) for d in args.exact_halo_child.split(",")]
+            block = exact_halo_mode(native.lib(), devices, shape, args.psf or cfg["psf"], V, args.steps, args.warmup,
+                                    devices[0])
+        print(json.dumps(block), flush=True)
+        return
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
@@ -588,7 +602,10 @@ def run_rank(args, world_env):
                     lib, [local_rank, local_rank], shape, psf_edge, V, args.steps, args.warmup, local_rank)
         except Exception as e:  # the headline number must survive a failing side measurement
             out["side_measurement_error"] = "%s: %s" % (type(e).__name__, e)
-    if use_dist and world > 1 and not args.no_side and args.all_ranks_on_device < 0:
+    # (MVN_BENCH_EXACT_DEVICES=0,0: rehearsal of this step on a one-GPU box, where every rank sits on one device)
+    exact_devices = os.environ.get("MVN_BENCH_EXACT_DEVICES") or (
+        ",".join(str(d) for d in range(world)) if args.all_ranks_on_device < 0 else "")
+    if use_dist and world > 1 and not args.no_side and exact_devices:
         # The N > 1 lines' `value` is the north-star mode (views sharded, one all-reduce per iteration: Jacobi).
         # The mode that keeps the REFERENCE's update order on N GPUs - dim0 slabs with a halo exchange, driven from
         # ONE process (rank 0) - rides along.  The other ranks wait on the HOST (a key in the rendezvous store, not
@@ -596,9 +613,26 @@ def run_rank(args, world_env):
         import datetime
         store = dist.distributed_c10d._get_default_store()
         if rank == 0:
+            # in a CHILD process with a time limit: this path has never run on more than one device (the builder's
+            # pool leases one GPU), and neither an error nor a hang in it may cost the line its headline
             try:
-                out["exact_halo_mode"] = exact_halo_mode(lib, list(range(world)), shape, psf_edge, V, args.steps,
-                                                         args.warmup, local_rank)
+                cmd = [sys.executable, os.path.abspath(__file__), "--exact-halo-child",
+                       exact_devices, "--config", str(args.config), "--steps", str(args.steps),
+                       "--warmup", str(args.warmup)]
+                if args.size:
+                    cmd += ["--size"] + [str(x) for x in args.size]
+                if args.views is not None:
+                    cmd += ["--views", str(args.views)]
+                if args.psf:
+                    cmd += ["--psf", str(args.psf)]
+                env = {k: v for k, v in os.environ.items()
+                       if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MVN_DEVICES")}
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and lines:
+                    out["exact_halo_mode"] = json.loads(lines[-1])
+                else:
+                    out["exact_halo_mode"] = {"error": "child rc %d: %s" % (r.returncode, r.stderr[-600:])}
             except Exception as e:  # the headline number must survive
                 out["exact_halo_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
             store.set("mvn_exact_halo_done", "1")

@@ -1073,7 +1073,8 @@ def _bench_problem(shape, V, psf_edge):
     return views, k1, k2, w, psi0
 
 
-@pytest.mark.parametrize("launch", ["two_ranks_gloo", "one_rank_nccl", "two_ranks_gloo_hostsync"])
+@pytest.mark.parametrize("launch", ["two_ranks_gloo", "one_rank_nccl", "two_ranks_gloo_hostsync",
+                                    "two_ranks_gloo_with_exact_halo_mode"])
 def test_bench_multi_rank_launch_path_vs_oracle(gpu, orc, tmp_path, launch):
     # `python bench.py --gpus 2 ...` exactly as typed (the parent spawns the ranks itself): 64^3, 3
     # views split 2 + 1 over two ranks that share device 0 (gloo; RCCL refuses two ranks on one
@@ -1086,7 +1087,10 @@ def test_bench_multi_rank_launch_path_vs_oracle(gpu, orc, tmp_path, launch):
     dump = str(tmp_path / "psi.npy")
     shape, V, psf, its = (64, 64, 64), 3, 9, 3
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--size", "64", "64", "64", "--views", str(V),
-           "--psf", str(psf), "--steps", str(its), "--warmup", "0", "--no-side", "--no-profile", "--dump-psi", dump]
+           "--psf", str(psf), "--steps", str(its), "--warmup", "0", "--no-profile", "--dump-psi", dump]
+    exact = launch.endswith("exact_halo_mode")
+    if not exact:
+        cmd += ["--no-side"]
     if launch == "one_rank_nccl":
         cmd += ["--gpus", "1", "--force-dist", "--backend", "nccl"]
     else:
@@ -1094,6 +1098,12 @@ def test_bench_multi_rank_launch_path_vs_oracle(gpu, orc, tmp_path, launch):
         if launch.endswith("hostsync"):
             cmd += ["--host-sync"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if exact:
+        # what an N > 1 line adds when the ranks sit on their own GPUs: rank 0 starts the slab mode over all devices
+        # as a child process with a time limit while the other ranks wait on the host; here both "devices" are GPU 0
+        env["MVN_BENCH_EXACT_DEVICES"] = "0,0"
+        for k in ("MVN_DIM0_DIRECT_MIN_ITEMS", "MVN_DIM0_DIRECT_MIN_PLANE"):
+            env.pop(k, None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     # the driver's contract: rank 0's stdout carries ONE JSON line and nothing else (RCCL's version
@@ -1106,6 +1116,10 @@ def test_bench_multi_rank_launch_path_vs_oracle(gpu, orc, tmp_path, launch):
     if launch != "one_rank_nccl":
         assert out["config"]["views_per_rank"] == [2, 1]
     assert "Jacobi" in out["config"]["update_mode"]
+    if exact:
+        e = out["exact_halo_mode"]
+        assert "error" not in e, e
+        assert e["devices"] == [0, 0] and e["parity"]["bit_equal"] and e["psi_finite_positive"], e
     got = np.load(dump)
     views, k1, k2, w, psi0 = _bench_problem(shape, V, psf)
     h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, its)

@@ -1029,7 +1029,7 @@ bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
              (long)env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
 }
 
-void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) {
+void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side, const RowsProducer* produce) {
   const Plan3D& P = *plan_;
   // One launch chain on stream_ - dim1 forward, direct leg, dim1 inverse, three launches - wherever the Nyquist bins
   // need no launches of their own: packed into the DC column, or (split layout) riding in the dim1 launches and in
@@ -1046,10 +1046,29 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
     const int H = halo_ranged() ? halo_planes_ : 0;
     const int own = P.L.d0 - 2 * H;
     const int view = (int)(&s - views_.data());
-    P.axis1(MVN_ST_FWD, (cfloat*)work_, wn(), stream_, prof, stream_, H, own);
-    if (halo_fn_) {  // the neighbours' planes arrive in the halo planes of the leg's input
+    const long d1 = P.L.d1;
+    auto rows = [&](int z0, int nz) {  // the pass that produces the planes [z0, z0 + nz) of this convolution's input
+      if (produce && *produce) (*produce)(H > 0 ? (long)z0 * d1 : 0, H > 0 ? (long)nz * d1 : -1);
+    };
+    if (produce && boundary_first()) {
+      // the planes the neighbours need FIRST - last-axis pass and dim1 pass of the H planes at either end of the own
+      // range -, then the call that lets them pull, then the interior: their copies run beside these two passes'
+      // interior and the leg's, not beside the leg's alone
+      rows(H, H);
+      rows(own, H);
+      P.axis1(MVN_ST_FWD, (cfloat*)work_, wn(), stream_, prof, stream_, H, H);
+      P.axis1(MVN_ST_FWD, (cfloat*)work_, wn(), stream_, nullptr, stream_, own, H);
       if (halo_drain_) be::stream_sync(stream_);
       halo_fn_(halo_user_, work_, view, i);
+      rows(2 * H, own - 2 * H);
+      P.axis1(MVN_ST_FWD, (cfloat*)work_, wn(), stream_, nullptr, stream_, 2 * H, own - 2 * H);
+    } else {
+      rows(H, own);
+      P.axis1(MVN_ST_FWD, (cfloat*)work_, wn(), stream_, prof, stream_, H, own);
+      if (halo_fn_) {  // the neighbours' planes arrive in the halo planes of the leg's input
+        if (halo_drain_) be::stream_sync(stream_);
+        halo_fn_(halo_user_, work_, view, i);
+      }
     }
     ensure_work2();
     const cfloat* in = (const cfloat*)work_;
@@ -1087,6 +1106,7 @@ void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side) 
   if (halo_fn_)
     throw std::logic_error("mvn: halo mode needs every PSF in the direct form (<= 33 planes) and Nyquist bins that need no "
                            "launches of their own (packed, or riding in the fixed-length dim1 kernels)");
+  if (produce && *produce) (*produce)(0, -1);  // (no plane ranges outside halo mode)
   if (!s.tap_k[i]) {
     P.middle_passes((cfloat*)work_, work_nyq_, (const cfloat*)(i == 0 ? s.spec1 : s.spec2), i == 0 ? s.nyq1 : s.nyq2,
                     stream_, prof, side, spec_tiled_);
@@ -1290,30 +1310,71 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   static const bool no_side = env_int("MVN_NO_SIDE_STREAM", 0) != 0;  // A/B knob
   static const size_t side_min_bytes = (size_t)env_int("MVN_SIDE_MIN_MB", 16) << 20;
   SideStream* side = (no_side || P.main_bytes() <= side_min_bytes) ? nullptr : &side_;
-  // (work_ / work_nyq_ are re-read after every middle(): the direct dim0 leg swaps the two work volumes)
-  // (halo mode: the rows of the own planes only, see middle())
-  const long r0 = halo_ranged() ? (long)halo_planes_ * P.L.d1 : 0;
-  const long nr = halo_ranged() ? (long)(P.L.d0 - 2 * halo_planes_) * P.L.d1 : -1;
-  if (!work_has_psi_spectrum_) P.rows_r2c(psi_, (cfloat*)work_, wn(), stream_, prof, r0, nr);
+  // The last-axis pass that PRODUCES a convolution's input is handed to middle() as a function of a row range: in
+  // halo mode with a split leg the planes next to the halos are produced (and dim1-transformed) FIRST, so that the
+  // neighbours can pull them while this slab still works on its interior (middle()); otherwise it is called once.
+  // (work_ / work_nyq_ are read when a producer is BUILT: the direct dim0 leg swaps the two work volumes, and a
+  // producer runs before the next leg.)
+  const Plan3D* Pp = plan_.get();
+  be::stream_t st = stream_;
+  RowsProducer p1;
+  if (pending_rows_) {  // the previous view update's fused update + forward pass, deferred (boundary-first order)
+    p1 = std::move(pending_rows_);
+    pending_rows_ = nullptr;
+  } else if (!work_has_psi_spectrum_) {
+    const float* psi = psi_;
+    cfloat* w = (cfloat*)work_;
+    cfloat* wnq = wn();
+    p1 = [=](long r0, long nr) { Pp->rows_r2c(psi, w, wnq, st, prof, r0, nr); };
+  }
   work_has_psi_spectrum_ = false;
-  middle(s, 0, prof, side);
+  middle(s, 0, prof, side, p1 ? &p1 : nullptr);
   arm(e1);
   // view / blurred, handed to convolution 2 as its last-axis spectrum
-  if (fuse) {
-    P.rows_c2r_r2c((cfloat*)work_, wn(), e1, stream_, prof, r0, nr);
-  } else {
-    P.rows_c2r((const cfloat*)work_, wn(), work_, e1, stream_, prof, r0, nr);
-    P.rows_r2c(work_, (cfloat*)work_, wn(), stream_, prof, r0, nr);
+  {
+    float* w = work_;
+    cfloat* wnq = wn();
+    RowsProducer p2 = [=](long r0, long nr) {
+      if (fuse) {
+        Pp->rows_c2r_r2c((cfloat*)w, wnq, e1, st, prof, r0, nr);
+      } else {
+        Pp->rows_c2r((const cfloat*)w, wnq, w, e1, st, prof, r0, nr);
+        Pp->rows_r2c(w, (cfloat*)w, wnq, st, prof, r0, nr);
+      }
+    };
+    // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
+    middle(s, 1, prof, side, &p2);
   }
-  // convolution 2: quotient (*) kernel2, then the psi update fused into the last pass
-  middle(s, 1, prof, side);
   arm(e2);
+  // (halo mode: the rows of the own planes only)
+  const long r0 = halo_ranged() ? (long)halo_planes_ * P.L.d1 : 0;
+  const long nr = halo_ranged() ? (long)(P.L.d0 - 2 * halo_planes_) * P.L.d1 : -1;
   if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
-    P.rows_c2r_r2c((cfloat*)work_, wn(), e2, stream_, prof, r0, nr);
+    float* w = work_;
+    cfloat* wnq = wn();
+    RowsProducer upd = [=](long a, long n) { Pp->rows_c2r_r2c((cfloat*)w, wnq, e2, st, prof, a, n); };
+    if (boundary_first())
+      pending_rows_ = std::move(upd);  // runs as the producer of the NEXT convolution, boundary planes first
+    else
+      upd(r0, nr);
     work_has_psi_spectrum_ = true;
   } else {
     P.rows_c2r((const cfloat*)work_, wn(), psi_, e2, stream_, prof, r0, nr);
   }
+}
+
+// a deferred producer also WRITES psi (the update epilogue): whoever leaves the loop runs it
+void Engine::flush_pending_rows() {
+  if (!pending_rows_) return;
+  const long d1 = plan_->L.d1;
+  const bool rg = halo_ranged();
+  pending_rows_(rg ? (long)halo_planes_ * d1 : 0, rg ? (long)(plan_->L.d0 - 2 * halo_planes_) * d1 : -1);
+  pending_rows_ = nullptr;
+}
+
+// the leg runs in two parts and the slab has planes that do not depend on its halos: boundary planes first
+bool Engine::boundary_first() const {
+  return halo_fn_ && halo_split_ && halo_ranged() && plan_->L.d0 - 2 * halo_planes_ > 2 * halo_planes_;
 }
 
 // Sweeps 2 .. n-1 of a call are identical launch sequences (every view update starts from the
@@ -1380,6 +1441,7 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
       conv_pair(v, lambda, min_value, MVN_EPI_UPDATE, 0, !last);
     }
   }
+  flush_pending_rows();
   work_has_psi_spectrum_ = false;
 }
 

@@ -11,6 +11,7 @@
 
 #include <array>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -371,7 +372,13 @@ class Engine {
   bool direct_form(const int* kdims);
   Plan3D* taps_plan(int kd);
   // dim1 forward -> dim0 leg (direct or fused FFT) -> dim1 inverse on the work volume, with kernel i of s
-  void middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side);
+  // `produce` (optional): the last-axis pass that produces this convolution's input, as a function of a row range
+  // (row0, nrows; nrows < 0 = all): launched by middle() - in one piece, or boundary planes first (halo mode)
+  typedef std::function<void(long, long)> RowsProducer;
+  void middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side, const RowsProducer* produce = nullptr);
+  RowsProducer pending_rows_;  // a fused update + forward pass deferred to the next convolution (boundary-first order)
+  void flush_pending_rows();
+  bool boundary_first() const;
   // zcount > 0: only the output planes [zbeg, zbeg + zcount); first = false: a further launch of the same leg
   void dim0_conv(const ViewSlot& s, int i, const cfloat* in, const cfloat* in_nyq, cfloat* out, cfloat* out_nyq,
                  Profiler* prof, be::stream_t sn, int zbeg = 0, int zcount = 0, bool first = true);

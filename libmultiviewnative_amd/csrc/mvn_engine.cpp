@@ -1387,6 +1387,7 @@ bool Engine::boundary_first() const {
 void Engine::iterate(int iterations, double lambda, float min_value) {
   be::set_device(device_);
   work_has_psi_spectrum_ = false;  // psi may have been replaced since the last call
+  pending_rows_ = nullptr;
   psi_spec_valid_ = false;
   decide_layout();
   const int V = (int)views_.size();

@@ -338,6 +338,7 @@ class Engine {
   void set_all_direct_hint(bool all) { packed_hint_ = all; }
   // a cached engine starts every ABI call from a clean per-call state
   void begin_call() {
+    pending_rows_ = nullptr;  // (a deferred pass of a call that failed half-way must never run on the next call's stacks)
     pipelined_ = false;
     quotient_guard_ = false;
     work_has_psi_spectrum_ = false;

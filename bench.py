@@ -467,7 +467,12 @@ def run_rank(args, world_env):
         KB = lambda k: kernel_bytes(k, d0, d1, d2, min(psf_edge, d0))
         prof = {k: v for k, v in prof.items() if v[1] and KB(k)[0] > 0}
         if prof:
-            kind = max(prof, key=lambda k: prof[k][0])
+            # the kernel with the largest total time; two kernels within 5 % of each other (the direct dim0 leg and the
+            # fused update pass are, at 512^3) would swap places from run to run: the one FURTHER from its roofline
+            # is reported then, the other one is named in `runner_up`
+            top = max(v[0] for v in prof.values())
+            close = [k for k in prof if prof[k][0] >= 0.95 * top]
+            kind = min(close, key=lambda k: KB(k)[0] / (prof[k][0] / max(prof[k][1], 1)))
             tot_ms, n = prof[kind]
             kb, B = KB(kind)
             avg_ms = tot_ms / max(n, 1)
@@ -476,6 +481,7 @@ def run_rank(args, world_env):
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                         "bytes_per_launch": kb,
+                        "runner_up": [k for k in close if k != kind],
                         "per_kernel": {k: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1],
                                            "GBps": round(KB(k)[0] / (v[0] / v[1] * 1e-3) / 1e9, 1)}
                                        for k, v in prof.items()}}

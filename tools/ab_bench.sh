@@ -10,7 +10,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         o = json.loads(l)
-        pk = o['roofline']['per_kernel']
+        pk = (o.get('roofline') or {}).get('per_kernel') or {}
         print('  %.3f ms/step  %.2f it/s ' % (o['ms_per_step'], o['value']), {k: v['avg_ms'] for k, v in pk.items()})
 " )
 done

@@ -100,6 +100,9 @@ def kernel_bytes(kind, d0, d1, d2, psf_planes=31):
         "axis0_fused": 3 * vol,         # read data, read PSF spectrum, write data
         # direct dim0 leg: read data, read the PSF's planes after the dim1/dim2 transforms, write data
         "axis0_direct": (2.0 + float(psf_planes) / d0) * vol,
+        # dim1 forward + direct dim0 leg + dim1 inverse in ONE pass over the line layout (csrc/mvn_mid_fused.hpp):
+        # read the half-spectrum, read the PSF's planes, write the half-spectrum
+        "mid_fused": (2.0 + float(psf_planes) / d0) * vol,
         "axis0_fwd": 2 * vol,
         "axis0_inv": 2 * vol,
         "nyquist": 2 * nyq,
@@ -532,12 +535,17 @@ def run_rank(args, world_env):
             # what the 8-pass pipeline actually moves per (view, iteration), DESIGN.md section 4: 22 volumes
             # with the fused FFT dim0 pass, 20 + 2 K / d0 with the direct dim0 leg (K PSF planes)
             direct = "axis0_direct" in prof
+            fused_mid = "mid_fused" in prof
             vols = 20.0 + 2.0 * min(psf_edge, d0) / d0 if direct else 22.0
+            if fused_mid:  # per convolution: last-axis pass out, ONE middle pass (2 volumes + taps), last-axis pass in
+                vols = 12.0 + 2.0 * min(psf_edge, d0) / d0
             actual = vols * vol * V / (ms_per_step * 1e-3) / 1e9
             out["whole_step_volumes_moved_per_view_iteration"] = round(vols, 3)
             out["whole_step_GBps_actual"] = round(actual, 1)
             out["whole_step_actual_frac_of_8TBps"] = round(actual / HBM_PEAK_GBS, 4)
-            out["dim0_leg"] = "direct (%d PSF planes)" % min(psf_edge, d0) if direct else "fused FFT pass"
+            out["dim0_leg"] = "direct (%d PSF planes)" % min(psf_edge, d0) if (direct or fused_mid) else "fused FFT pass"
+            out["middle_passes"] = ("one (dim1 forward + direct dim0 leg + dim1 inverse fused, line layout)" if fused_mid
+                                    else "three")
         # The N > 1 lines time the simultaneous (Jacobi) loop, this line's `value` the reference-order
         # sequential sweep: a scaling series must be read against the SAME loop on one rank, so the
         # N = 1 line carries that rate too (same engine, same stacks, same step count).

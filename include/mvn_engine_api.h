@@ -55,6 +55,9 @@ MVN_API int mvn_psf_cache_counters(long out[2]);
 /* passes launched through the long-line (16-column, split-window) kernels since process start
  * (test / diagnostics; MVN_NO_SPLIT=1 keeps the 8-column kernels) */
 MVN_API long mvn_split_launch_count(void);
+/* launches of the fused middle pass (dim1 forward + direct dim0 leg + dim1 inverse in one pass over the line layout;
+   csrc/mvn_mid_fused.hpp) since process start: tests check that the shapes that have it take it */
+MVN_API long mvn_mid_fused_launch_count(void);
 /* inplace_gpu_deconvolve calls that ran as dim0 slabs on the devices of MVN_DEVICES (multiviewnative.h) since
  * process start - a call that could not be cut that way ran on one device and is not counted */
 MVN_API long mvn_multi_device_calls(void);

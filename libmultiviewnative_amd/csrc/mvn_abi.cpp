@@ -473,6 +473,10 @@ static void deconvolve_call(imageType* psi, const workspace& input, int device, 
       for (int v = 0; v < V && all; ++v)
         all = eng.would_be_direct(input.data_[v].kernel1_dims_) && eng.would_be_direct(input.data_[v].kernel2_dims_);
       eng.set_all_direct_hint(all);
+      bool lines = all;  // ... and through the fused middle pass (mvn_mid_fused.hpp)
+      for (int v = 0; v < V && lines; ++v)
+        lines = eng.would_be_lines(input.data_[v].kernel1_dims_) && eng.would_be_lines(input.data_[v].kernel2_dims_);
+      eng.set_all_lines_hint(lines);
     }
     lap("allocate view buffers");
     std::unique_lock<std::mutex> pcie(upload_mutex(dev));  // handed to the uploader thread's scope below
@@ -913,6 +917,7 @@ int mvn_release_cached_engines(void) {
 }
 
 long mvn_split_launch_count(void) { return be::split_launch_count(); }
+long mvn_mid_fused_launch_count(void) { return be::mid_fused_launch_count(); }
 long mvn_multi_device_calls(void) { return g_multi_calls.load(); }
 
 // ---- resident group of slab engines (what MVN_DEVICES runs inside inplace_gpu_deconvolve) -----

@@ -12,6 +12,7 @@
 
 #include "mvn_pass_bodies.hpp"
 #include "mvn_dim0_direct.hpp"
+#include "mvn_mid_fused.hpp"
 
 namespace mvn {
 namespace be {
@@ -88,6 +89,8 @@ void launch_rows_c2r_r2c(const RowsParams& p, long ntiles, int nthreads, size_t 
                          stream_t s);
 // launches that went through the long-line (split-window, 16-column) kernels since process start
 long split_launch_count();
+// launches of the fused middle pass (mvn_mid_fused.hpp) since process start
+long mid_fused_launch_count();
 // `rider` (plain fixed-length passes only): a second pass of the same mode with tiles of ONE line (T = 1, run-time
 // radix body) - the lines of the Nyquist plane, taken by rider->tiles_per_outer further workgroups of the same launch
 void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads,
@@ -96,6 +99,10 @@ void launch_strided(int mode, const StridedParams& p, long nblocks, int nthreads
 // the dim0 leg of a convolution as a direct cyclic convolution with the PSF's few planes
 // (mvn_dim0_direct.hpp); p.k must satisfy mvn_dim0_direct_possible(p.k, p.d0)
 void launch_dim0_direct(const Dim0DirectParams& p, stream_t s);
+
+// dim1 forward + direct dim0 leg + dim1 inverse in ONE pass over a half-spectrum in the line layout, or (p.mode ==
+// MF_TAPS) the forward transform of a PSF's planes into the bin order that pass filters in (mvn_mid_fused.hpp)
+void launch_mid_fused(const MidFusedParams& p, stream_t s);
 
 // target[(z-kz/2 mod D0, y-ky/2 mod D1, x-kx/2 mod D2)] = kernel[z][y][x] * scale
 // (device-side wrapped_insert_at_point, inc/padd_utils.h:11-40; the reference's GPU twin is

@@ -154,7 +154,7 @@ static bool emu_wave_rows(const RowsParams& p, int kind_bit) {
   const char* e = std::getenv("MVN_NO_WAVE_ROWS");
   const char* m = std::getenv("MVN_WAVE_ROWS_MASK");
   const int mask = m && *m ? std::atoi(m) : 31;
-  return !(e && *e && std::strcmp(e, "0") != 0) && (mask & kind_bit) && p.fixed && p.h == WrCfg::H &&
+  return !(e && *e && std::strcmp(e, "0") != 0) && (mask & kind_bit) && p.fixed && !p.lines && p.h == WrCfg::H &&
          p.C == WrCfg::H;
 }
 
@@ -196,6 +196,80 @@ static long emu_rows_grid(long ntiles) {
   return FxRowsCfg<H>::WALK && ntiles > 2 ? (ntiles + 2) / 3 : ntiles;
 }
 
+// line-layout forms of the fixed last-axis kernels (H = 256), KIND 0 r2c, 1 c2r, 2 fused
+static void emu_rows_lines(const RowsParams& p, long ntiles, int kind) {
+  constexpr int H = 256;
+  typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+  if (!fx_rows_lines_ok<H>() || !p.fixed || p.h != H || p.C != H || !p.nyq_packed || p.lines_d1 < 1 ||
+      p.lines_d1 % FxRowsCfg<H>::T || p.row_base % FxRowsCfg<H>::T || p.rows != ntiles * FxRowsCfg<H>::T)
+    throw std::invalid_argument("mvn: line-layout last-axis pass outside its range");
+#pragma omp parallel
+  {
+    std::vector<char> lds(sizeof(cfloat) * FxRowsCfg<H>::lds_cfloats + 64);
+    std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+    for (long t = 0; t < ntiles; ++t) {
+      cfloat* l = (cfloat*)lds.data();
+      if (kind == 0) {
+        fx_rows_run<H, 0, MVN_EPI_STORE, Ctx, true>(p, t, ntiles, l, *ctx);
+      } else if (kind == 1) {
+        switch (p.epi.mode) {
+          case MVN_EPI_DIVIDE: fx_rows_run<H, 1, MVN_EPI_DIVIDE, Ctx, true>(p, t, ntiles, l, *ctx); break;
+          case MVN_EPI_UPDATE: fx_rows_run<H, 1, MVN_EPI_UPDATE, Ctx, true>(p, t, ntiles, l, *ctx); break;
+          case MVN_EPI_DELTA: fx_rows_run<H, 1, MVN_EPI_DELTA, Ctx, true>(p, t, ntiles, l, *ctx); break;
+          default: fx_rows_run<H, 1, MVN_EPI_STORE, Ctx, true>(p, t, ntiles, l, *ctx); break;
+        }
+      } else {
+        switch (p.epi.mode) {
+          case MVN_EPI_DIVIDE: fx_rows_run<H, 2, MVN_EPI_DIVIDE, Ctx, true>(p, t, ntiles, l, *ctx); break;
+          case MVN_EPI_UPDATE: fx_rows_run<H, 2, MVN_EPI_UPDATE, Ctx, true>(p, t, ntiles, l, *ctx); break;
+          default: fx_rows_run<H, 2, MVN_EPI_STORE, Ctx, true>(p, t, ntiles, l, *ctx); break;
+        }
+      }
+    }
+  }
+}
+
+static std::atomic<long> g_mid_fused_launches{0};
+long mid_fused_launch_count() { return g_mid_fused_launches.load(); }
+
+// the fused middle pass (mvn_mid_fused.hpp), one workgroup after the other
+template <int K>
+static void emu_mid_fused(const MidFusedParams& p) {
+  typedef FxCtx<MfRegs<K>, MF_NT> Ctx;
+  const long blocks = mf_blocks(p);
+#pragma omp parallel
+  {
+    std::vector<cfloat> lds(MF_LDS_CFLOATS + 8);
+    std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+    for (long b = 0; b < blocks; ++b) mf_body<K>(p, b, lds.data(), *ctx);
+  }
+}
+#define MVN_MF_TAP_COUNTS(X) X(1) X(3) X(5) X(7) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31)
+void launch_mid_fused(const MidFusedParams& p, stream_t) {
+  mf_check(p);
+  if (p.mode == MF_TAPS) {
+    typedef FxCtx<MfRegs<1>, MF_NT> Ctx;
+    const long blocks = mf_blocks(p);
+#pragma omp parallel
+    {
+      std::vector<cfloat> lds(MF_LDS_CFLOATS + 8);
+      std::unique_ptr<Ctx> ctx(new Ctx());
+#pragma omp for schedule(static)
+      for (long b = 0; b < blocks; ++b) mf_taps_body(p, b, lds.data(), *ctx);
+    }
+    return;
+  }
+  ++g_mid_fused_launches;
+  switch (mvn_dim0_taps_template(p.k)) {
+#define X(K) case K: emu_mid_fused<K>(p); break;
+    MVN_MF_TAP_COUNTS(X)
+#undef X
+    default: throw std::invalid_argument("mvn: no fused middle pass for this tap count");
+  }
+}
+
 template <int H>
 static void emu_rows_fused(const RowsParams& p, long ntiles) {
   typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
@@ -219,6 +293,7 @@ static void emu_rows_fused(const RowsParams& p, long ntiles) {
 void launch_rows_c2r_r2c(const RowsParams& p0, long ntiles, int, size_t lds_bytes, stream_t) {
   RowsParams p = p0;
   mvn_arm_poison(p.epi);  // (the device kernels do this at their entry)
+  if (p.lines) return emu_rows_lines(p, ntiles, 2);
   if (emu_wave_rows(p, p.epi.mode == MVN_EPI_DIVIDE ? 4 : 8)) return emu_wave_rows_mode<MVN_WR_C2R_R2C>(p);
   if (!p.fixed) {  // run-time-radix form of the fused pass (any even d2)
 #pragma omp parallel
@@ -350,6 +425,7 @@ static bool emu_strided_fixed_dispatch(int mode, const StridedParams& p, long nb
 
 void launch_rows_r2c(const RowsParams& p, bool even, long ntiles, int, size_t lds_bytes,
                      stream_t) {
+  if (p.lines) return emu_rows_lines(p, ntiles, 0);
   if (emu_wave_rows(p, 1)) return emu_wave_rows_run<MVN_WR_R2C, MVN_EPI_STORE>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, true)) throw std::invalid_argument("mvn: no fixed kernel");
@@ -374,6 +450,7 @@ void launch_rows_c2r(const RowsParams& p0, bool even, long ntiles, int, size_t l
                      stream_t) {
   RowsParams p = p0;
   mvn_arm_poison(p.epi);
+  if (p.lines) return emu_rows_lines(p, ntiles, 1);
   if (emu_wave_rows(p, p.epi.mode == MVN_EPI_DELTA ? 16 : 2)) return emu_wave_rows_mode<MVN_WR_C2R>(p);
   if (p.fixed) {
     if (!emu_rows_fixed_dispatch(p, ntiles, false)) throw std::invalid_argument("mvn: no fixed kernel");

@@ -21,7 +21,7 @@ const char* kernel_kind_name(int k) {
   static const char* names[KK_COUNT] = {"rows_r2c",    "rows_c2r",  "rows_fused_div",
                                         "rows_fused_upd", "axis1_fwd", "axis1_inv",
                                         "axis0_fused", "axis0_fwd",  "axis0_inv",
-                                        "nyquist",     "other",     "axis0_direct"};
+                                        "nyquist",     "other",     "axis0_direct", "mid_fused"};
   return (k >= 0 && k < KK_COUNT) ? names[k] : "?";
 }
 
@@ -265,11 +265,25 @@ static long rows_in_range(const Plan3D& P, long row0, long nrows) {
   return n;
 }
 
+// a last-axis pass on the line layout: the complex pointer stays at the volume's first element, the kernel gets the
+// first row instead
+static void lines_args(const Plan3D& P, RowsParams& p, long row0, const void* nyq, const void* real_side,
+                       const void* cplx_side) {
+  if (!P.lines_capable()) throw std::logic_error("mvn: this shape has no line-layout last-axis passes");
+  if (nyq) throw std::logic_error("mvn: the line layout keeps the Nyquist bins in the DC column");
+  if (real_side && real_side == cplx_side) throw std::logic_error("mvn: a plain last-axis pass on the line layout is out of place");
+  p.lines = 1;
+  p.lines_d1 = P.L.d1;
+  p.row_base = row0;
+  p.nyq_packed = 1;
+}
+
 void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::stream_t s,
-                      Profiler* prof, long row0, long nrows) const {
+                      Profiler* prof, long row0, long nrows, bool lines) const {
   const long R = rows_in_range(*this, row0, nrows);
+  const void* real0 = in_real;
   in_real += row0 * L.RP;
-  out += row0 * L.C;
+  if (!lines) out += row0 * L.C;
   if (out_nyq) out_nyq += row0;
   RowsParams p;
   std::memset(&p, 0, sizeof(p));
@@ -290,6 +304,7 @@ void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::st
   p.out_cplx = out;
   p.out_nyq = out_nyq;
   p.nyq_packed = (L.even && !out_nyq) ? 1 : 0;  // no Nyquist plane given: DC + i Nyquist in column 0
+  if (lines) lines_args(*this, p, row0, out_nyq, real0, out);
   ProfScope ps(prof, KK_ROWS_R2C, s);
   if (fx_rows) {
     p.fixed = 1;
@@ -303,9 +318,11 @@ void Plan3D::rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::st
 
 void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
                       const EpilogueParams& epi_all, be::stream_t s, Profiler* prof, long row0,
-                      long nrows) const {
+                      long nrows, bool lines) const {
   const long R = rows_in_range(*this, row0, nrows);
-  in += row0 * L.C;
+  const void* cplx0 = in;
+  const void* real0 = out_real;
+  if (!lines) in += row0 * L.C;
   if (in_nyq) in_nyq += row0;
   if (out_real) out_real += row0 * L.RP;
   EpilogueParams epi = epi_all;
@@ -332,6 +349,7 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
   p.in_cplx = in;
   p.in_nyq = in_nyq;
   p.nyq_packed = (L.even && !in_nyq) ? 1 : 0;
+  if (lines) lines_args(*this, p, row0, in_nyq, real0, cplx0);
   p.out_real = out_real;
   p.epi = epi;
   if (!p.epi.poison) {
@@ -350,10 +368,10 @@ void Plan3D::rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
 }
 
 void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi_all, be::stream_t s,
-                          Profiler* prof, long row0, long nrows) const {
+                          Profiler* prof, long row0, long nrows, bool lines) const {
   if (!L.even) throw std::logic_error("mvn: rows_c2r_r2c needs an even last extent");
   const long R = rows_in_range(*this, row0, nrows);
-  data += row0 * L.C;
+  if (!lines) data += row0 * L.C;
   if (nyq) nyq += row0;
   EpilogueParams epi = epi_all;
   const long eoff = row0 * L.RP;
@@ -375,6 +393,7 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi_a
   p.out_cplx = data;
   p.out_nyq = nyq;
   p.nyq_packed = nyq ? 0 : 1;
+  if (lines) lines_args(*this, p, row0, nyq, nullptr, nullptr);
   p.epi = epi;
   if (!p.epi.poison) {
     p.epi.poison = no_poison;
@@ -395,6 +414,47 @@ void Plan3D::rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi_a
   p.Cmul = mvn_fastdiv_mul((unsigned)L.C);
   const long ntiles = (R + p.T - 1) / p.T;
   be::launch_rows_c2r_r2c(p, ntiles, g_rows.threads, g_rows.lds_bytes, s);
+}
+
+bool Plan3D::lines_capable() const {
+  return fx_rows && L.even && L.h == 256 && L.C == 256 && L.d1 == MF_N1 && gx_rows.T == 16 && !ax1.host.bluestein &&
+         ax1.host.nfft == MF_N1;
+}
+
+void Plan3D::mid_fused(const cfloat* in, cfloat* out, const cfloat* taps, int k, int kd, unsigned* poison,
+                       unsigned poison_epoch, be::stream_t s, Profiler* prof) const {
+  if (!lines_capable()) throw std::logic_error("mvn: this shape has no fused middle pass");
+  MidFusedParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.in = in;
+  p.out = out;
+  p.taps = taps;
+  p.kd = kd;
+  p.tw = ax1.view.tw;
+  p.d0 = L.d0;
+  p.H = L.C;
+  p.k = k;
+  p.h = k / 2;
+  p.seg = 0;  // whole columns: C = 256 workgroups, one per CU of an MI355X
+  p.mode = MF_CONV;
+  p.packed = 1;
+  p.poison = poison;
+  p.poison_epoch = poison_epoch;
+  ProfScope ps(prof, KK_MID_FUSED, s);
+  be::launch_mid_fused(p, s);
+}
+
+void Plan3D::taps_to_lines(cfloat* taps, be::stream_t s) const {
+  if (!lines_capable()) throw std::logic_error("mvn: this shape has no fused middle pass");
+  MidFusedParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.in = taps;
+  p.out = taps;
+  p.tw = ax1.view.tw;
+  p.d0 = L.d0;
+  p.H = L.C;
+  p.mode = MF_TAPS;
+  be::launch_mid_fused(p, s);
 }
 
 static StridedParams make_strided(const DevAxis& ax, const PassGeom& g, cfloat* data,
@@ -644,7 +704,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   side_.create();
   const size_t mb = plan_->main_bytes();
   psi_ = (float*)be::dmalloc(mb);
-  work_ = (float*)be::dmalloc(mb);
+  work_ = work_alloc_ = (float*)be::dmalloc(mb);
   be::dzero(psi_, mb, stream_);
   be::dzero(work_, mb, stream_);
   if (plan_->nyq_bytes()) work_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
@@ -657,6 +717,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   // (MVN_D0_MAX_TAPS = 33 are instantiated); measured at 512^3 x 6 views on MI355X (profiles/r03_dim0_direct.md)
   // the whole iteration is 6.7 / 4.1 % faster than with the fused FFT pass at 15 / 31 planes
   direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
+  lines_capable_ = plan_->lines_capable() && env_int("MVN_MID_FUSED", 1) != 0;
   direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
   direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 131072);  // see direct_ok_for()
   direct_min_items_ = env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
@@ -694,12 +755,15 @@ Engine::~Engine() {
     for (int i = 0; i < 2; ++i) {
       be::dfree(views_[v].taps[i]);
       be::dfree(views_[v].taps_nyq[i]);
+      be::dfree(views_[v].taps_l[i]);
+      be::dfree(views_[v].taps_scr[i]);
     }
   }
   be::dfree(psi_);
-  be::dfree(work_);
+  // (work_ and work2_ swap roles at every direct leg: freed by their allocations, not by their roles)
+  be::dfree(work_alloc_);
   be::dfree(work_nyq_);
-  be::dfree(work2_);
+  be::dfree(work2_alloc_);
   be::dfree(work2_nyq_);
   be::dfree(psi_spec_);
   be::dfree(psi_spec_nyq_);
@@ -859,8 +923,12 @@ void Engine::prepare_psf(ViewSlot& s, int i, const float* d_kernel, const int* k
       s.taps_nyq[i] = nullptr;
       s.taps[i] = (float*)be::dmalloc(tp->main_bytes());
       if (tp->nyq_bytes()) s.taps_nyq[i] = (cfloat*)be::dmalloc(tp->nyq_bytes());
+      be::dfree(s.taps_l[i]);
+      be::dfree(s.taps_scr[i]);
+      s.taps_l[i] = s.taps_scr[i] = nullptr;
       s.tap_kd[i] = kd;
     }
+    s.taps_l_ok[i] = false;
     s.tap_k[i] = 0;  // not valid until the launches below are enqueued
     // dims 1 and 2 are transformed (un-normalised, both ways), dim0 is not: 1 / (d1 d2)
     const float scale = (float)(1.0 / ((double)L.d1 * (double)L.d2));
@@ -868,6 +936,18 @@ void Engine::prepare_psf(ViewSlot& s, int i, const float* d_kernel, const int* k
     be::launch_scatter_psf(d_kernel, kdims[0], kdims[1], kdims[2], s.taps[i], kd, L.d1, L.d2, tp->L.RP, scale, st);
     tp->rows_r2c(s.taps[i], (cfloat*)s.taps[i], s.taps_nyq[i], st, nullptr);
     tp->axis1(MVN_ST_FWD, (cfloat*)s.taps[i], s.taps_nyq[i], st, nullptr);
+    if (lines_capable_ && tp->lines_capable() && mvn_dim0_taps_template(kdims[0]) <= 31) {
+      // the same planes for the fused middle pass: line layout, Nyquist bins packed, its own bin order along dim1
+      if (!s.taps_l[i]) {
+        s.taps_l[i] = (float*)be::dmalloc(tp->main_bytes());
+        s.taps_scr[i] = (float*)be::dmalloc(tp->main_bytes());
+      }
+      be::dzero(s.taps_scr[i], tp->main_bytes(), st);
+      be::launch_scatter_psf(d_kernel, kdims[0], kdims[1], kdims[2], s.taps_scr[i], kd, L.d1, L.d2, tp->L.RP, scale, st);
+      tp->rows_r2c(s.taps_scr[i], (cfloat*)s.taps_l[i], nullptr, st, nullptr, 0, -1, true);
+      tp->taps_to_lines((cfloat*)s.taps_l[i], st);
+      s.taps_l_ok[i] = true;
+    }
     s.tap_k[i] = kdims[0];
     return;
   }
@@ -879,6 +959,7 @@ void Engine::prepare_psf(ViewSlot& s, int i, const float* d_kernel, const int* k
     if (plan_->nyq_bytes()) nyq = (cfloat*)be::dmalloc(plan_->nyq_bytes());
   }
   s.tap_k[i] = 0;
+  s.taps_l_ok[i] = false;
   if (spec_tiled_ && !scratch) {
     if (!staging) throw std::logic_error("mvn: spectrum scratch missing");
     if (!stage_spec_scratch_) {  // the main thread iterates on the work volume meanwhile: own scratch, freed
@@ -894,7 +975,12 @@ void Engine::prepare_psf(ViewSlot& s, int i, const float* d_kernel, const int* k
 
 void Engine::ensure_work2() {
   if (work2_) return;
-  work2_ = (float*)be::dmalloc(plan_->main_bytes());
+  size_t skew = 0;
+#ifdef MVN_EXPERIMENTS  // variant builds only: the second work volume displaced against the first (DRAM bank / channel phase)
+  skew = (size_t)env_int("MVN_WORK2_SKEW_KB", 0) * 1024;
+#endif
+  work2_alloc_ = (float*)be::dmalloc(plan_->main_bytes() + skew);
+  work2_ = work2_alloc_ + skew / sizeof(float);
   if (plan_->nyq_bytes()) work2_nyq_ = (cfloat*)be::dmalloc(plan_->nyq_bytes());
 }
 
@@ -1011,9 +1097,48 @@ void Engine::decide_layout() {
   const bool was = packed_;
   packed_ = want && (pipelined_ ? packed_hint_ : all_direct());
   if (was != packed_) ++graph_gen_;  // ... and the layout
+  lines_ = false;  // (only the sequential sweep asks for the line layout: decide_lines())
 }
 
 bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
+
+bool Engine::would_be_lines(const int* kdims) {
+  return lines_capable_ && direct_form(kdims) && mvn_dim0_taps_template(kdims[0]) <= 31 &&
+         taps_plan(((kdims[0] + 1 + 15) / 16) * 16)->lines_capable();
+}
+
+// The sequential sweep takes the fused middle pass when the shape has it, every kernel is held in the form it
+// reads and nothing else lays claim to the layout of the work volumes (halo exchanges copy planes of the row-major
+// spectrum).  Decided per iterate() call, behind decide_layout().
+void Engine::decide_lines() {
+  const bool was = lines_last_sweep_;
+  bool all = lines_capable_ && !halo_fn_ && halo_planes_ == 0 && !views_.empty();
+  if (all) {
+    if (pipelined_) {
+      all = lines_hint_;
+    } else {
+      for (size_t v = 0; v < views_.size() && all; ++v)
+        all = views_[v].set && views_[v].tap_k[0] && views_[v].tap_k[1] && views_[v].taps_l_ok[0] && views_[v].taps_l_ok[1];
+    }
+  }
+  lines_ = lines_last_sweep_ = all;
+  if (was != lines_) ++graph_gen_;  // (a captured sweep holds the form of its passes)
+}
+
+// the three middle passes of convolution i as ONE: work_ -> work2_ (line layout), the volumes swap roles
+void Engine::mid_fused_conv(const ViewSlot& s, int i, Profiler* prof) {
+  if (!s.taps_l_ok[i] || !s.tap_k[i]) throw std::logic_error("mvn: fused middle pass with a kernel that is not in its form");
+  ensure_work2();
+  if (++epoch_ == 0x7fffffffu) {
+    be::dzero(poison_, sizeof(unsigned), stream_);
+    epoch_ = 1;
+  }
+  armed_epoch_ = epoch_;
+  plan_->mid_fused((const cfloat*)work_, (cfloat*)work2_, (const cfloat*)s.taps_l[i], s.tap_k[i], s.tap_kd[i], poison_,
+                   epoch_, stream_, prof);
+  std::swap(work_, work2_);
+  std::swap(work_nyq_, work2_nyq_);
+}
 
 // Is the direct dim0 leg to be used for PSFs of k0 planes on a (d0, d1, d2) volume?  Switches: MVN_DIM0_DIRECT,
 // MVN_DIM0_DIRECT_MAX (deepest PSF, <= 33), MVN_DIM0_DIRECT_MIN_PLANE (work items a launch should have: columns
@@ -1031,6 +1156,11 @@ bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
 
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side, const RowsProducer* produce) {
   const Plan3D& P = *plan_;
+  if (lines_) {
+    if (produce && *produce) (*produce)(0, -1);
+    mid_fused_conv(s, i, prof);
+    return;
+  }
   // One launch chain on stream_ - dim1 forward, direct leg, dim1 inverse, three launches - wherever the Nyquist bins
   // need no launches of their own: packed into the DC column, or (split layout) riding in the dim1 launches and in
   // the leg's.
@@ -1325,7 +1455,8 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
     const float* psi = psi_;
     cfloat* w = (cfloat*)work_;
     cfloat* wnq = wn();
-    p1 = [=](long r0, long nr) { Pp->rows_r2c(psi, w, wnq, st, prof, r0, nr); };
+    const bool ln = lines_;
+    p1 = [=](long r0, long nr) { Pp->rows_r2c(psi, w, ln ? nullptr : wnq, st, prof, r0, nr, ln); };
   }
   work_has_psi_spectrum_ = false;
   middle(s, 0, prof, side, p1 ? &p1 : nullptr);
@@ -1334,8 +1465,11 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   {
     float* w = work_;
     cfloat* wnq = wn();
+    const bool ln = lines_;
     RowsProducer p2 = [=](long r0, long nr) {
-      if (fuse) {
+      if (ln) {
+        Pp->rows_c2r_r2c((cfloat*)w, nullptr, e1, st, prof, r0, nr, true);
+      } else if (fuse) {
         Pp->rows_c2r_r2c((cfloat*)w, wnq, e1, st, prof, r0, nr);
       } else {
         Pp->rows_c2r((const cfloat*)w, wnq, w, e1, st, prof, r0, nr);
@@ -1352,14 +1486,15 @@ void Engine::conv_pair(int v, double lambda, float min_value, int final_mode, in
   if (fuse && feed_next && final_mode == MVN_EPI_UPDATE) {
     float* w = work_;
     cfloat* wnq = wn();
-    RowsProducer upd = [=](long a, long n) { Pp->rows_c2r_r2c((cfloat*)w, wnq, e2, st, prof, a, n); };
+    const bool ln = lines_;
+    RowsProducer upd = [=](long a, long n) { Pp->rows_c2r_r2c((cfloat*)w, ln ? nullptr : wnq, e2, st, prof, a, n, ln); };
     if (boundary_first())
       pending_rows_ = std::move(upd);  // runs as the producer of the NEXT convolution, boundary planes first
     else
       upd(r0, nr);
     work_has_psi_spectrum_ = true;
   } else {
-    P.rows_c2r((const cfloat*)work_, wn(), psi_, e2, stream_, prof, r0, nr);
+    P.rows_c2r((const cfloat*)work_, lines_ ? nullptr : wn(), psi_, e2, stream_, prof, r0, nr, lines_);
   }
 }
 
@@ -1390,6 +1525,7 @@ void Engine::iterate(int iterations, double lambda, float min_value) {
   pending_rows_ = nullptr;
   psi_spec_valid_ = false;
   decide_layout();
+  decide_lines();
   const int V = (int)views_.size();
   static const bool graphs_on = env_int("MVN_GRAPH", 0) != 0 && be::graphs_supported();
   static const size_t graph_max_bytes = (size_t)env_int("MVN_GRAPH_MAX_MB", 160) << 20;

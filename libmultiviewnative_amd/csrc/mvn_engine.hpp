@@ -36,6 +36,7 @@ enum KernelKind {
   KK_NYQ,
   KK_OTHER,
   KK_AXIS0_DIRECT,  // dim0 leg as a direct convolution with the PSF's planes (mvn_dim0_direct.hpp)
+  KK_MID_FUSED,     // dim1 forward + direct dim0 leg + dim1 inverse in one pass (mvn_mid_fused.hpp)
   KK_COUNT
 };
 const char* kernel_kind_name(int k);
@@ -123,11 +124,22 @@ class Plan3D {
   // last-axis pass touches is indexed by row, so a range is the same launch on shifted pointers.
   // The view-sharded driver uses it to produce and consume the correction chunk by chunk under
   // the all-reduce (Engine::compute_delta_chunk / apply_delta_chunk).
+  // `lines`: the half-spectrum is in the LINE layout of the fused middle pass ([plane][position][row], Nyquist bins
+  // packed: the Nyquist pointer must be null); out-of-place for rows_r2c, in place tile by tile for rows_c2r_r2c
   void rows_r2c(const float* in_real, cfloat* out, cfloat* out_nyq, be::stream_t s,
-                Profiler* prof = nullptr, long row0 = 0, long nrows = -1) const;
+                Profiler* prof = nullptr, long row0 = 0, long nrows = -1, bool lines = false) const;
   void rows_c2r(const cfloat* in, const cfloat* in_nyq, float* out_real,
                 const EpilogueParams& epi, be::stream_t s, Profiler* prof = nullptr,
-                long row0 = 0, long nrows = -1) const;
+                long row0 = 0, long nrows = -1, bool lines = false) const;
+  // the shape has the line-layout forms of the last-axis kernels and the fused middle pass (d1 = d2 = 512)
+  bool lines_capable() const;
+  // dim1 forward + K-tap direct convolution along dim0 + dim1 inverse, `in` -> `out` (both in the line layout);
+  // taps: [kd][C][d1] as prepared by taps_to_lines()
+  void mid_fused(const cfloat* in, cfloat* out, const cfloat* taps, int k, int kd, unsigned* poison,
+                 unsigned poison_epoch, be::stream_t s, Profiler* prof = nullptr) const;
+  // PSF planes after the last-axis pass (line layout, this plan = the small plan of the tap arrays) -> transformed
+  // along dim1 into the bin order mid_fused() filters in; in place
+  void taps_to_lines(cfloat* taps, be::stream_t s) const;
   // rows per tile of the last-axis passes and whether a launch needs whole tiles
   int rows_tile() const { return fx_rows ? gx_rows.T : g_rows.T; }
   bool rows_need_full_tiles() const { return fx_rows; }
@@ -135,7 +147,7 @@ class Plan3D {
   // (data, nyq); epi.mode is DIVIDE, UPDATE or STORE
   bool can_fuse_rows() const { return L.even; }
   void rows_c2r_r2c(cfloat* data, cfloat* nyq, const EpilogueParams& epi, be::stream_t s,
-                    Profiler* prof = nullptr, long row0 = 0, long nrows = -1) const;
+                    Profiler* prof = nullptr, long row0 = 0, long nrows = -1, bool lines = false) const;
   // strided passes on the main array and its Nyquist plane; mode = MvnStridedMode
   // `s_nyq` (default: s) is the stream of the small Nyquist-plane launches; giving them their own
   // stream lets the 2 MB plane ride along with the full-volume passes (see SideStream)
@@ -214,6 +226,12 @@ struct ViewSlot {
   cfloat* taps_nyq[2] = {nullptr, nullptr};
   int tap_k[2] = {0, 0};
   int tap_kd[2] = {0, 0};
+  // the same PSF planes for the fused middle pass (mvn_mid_fused.hpp): [tap_kd][C][d1], Nyquist bins packed, bins
+  // along dim1 in that pass's own order; taps_scr: the scattered PSF the last-axis pass reads (it cannot run in
+  // place into the line layout).  taps_l_ok: valid for the kernel tap_k / tap_kd describe.
+  float* taps_l[2] = {nullptr, nullptr};
+  float* taps_scr[2] = {nullptr, nullptr};
+  bool taps_l_ok[2] = {false, false};
 };
 
 class Engine {
@@ -336,6 +354,11 @@ class Engine {
   // does a volume of this size keep its Nyquist bins packed in the DC column (when every PSF is in the direct form)?
   static bool packed_layout_for(size_t volume_bytes);
   void set_all_direct_hint(bool all) { packed_hint_ = all; }
+  // the fused middle pass (mvn_mid_fused.hpp): will a kernel of these extents run through it? / every kernel of
+  // the call will (pipelined calls: the loop starts before the last view has been staged)
+  bool would_be_lines(const int* kdims);
+  void set_all_lines_hint(bool all) { lines_hint_ = all; }
+  bool lines_in_use() const { return lines_; }
   // a cached engine starts every ABI call from a clean per-call state
   void begin_call() {
     pending_rows_ = nullptr;  // (a deferred pass of a call that failed half-way must never run on the next call's stacks)
@@ -392,6 +415,11 @@ class Engine {
   cfloat* wn() const { return packed_ ? nullptr : work_nyq_; }
   cfloat* pn() const { return packed_ ? nullptr : psi_spec_nyq_; }
   bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
+  // the sequential sweep runs its convolutions as last-axis pass -> fused middle pass -> last-axis pass on the
+  // line layout (decided per iterate() call; every other loop form keeps the three-pass middle)
+  bool lines_capable_ = false, lines_ = false, lines_hint_ = false, lines_last_sweep_ = false;
+  void decide_lines();
+  void mid_fused_conv(const ViewSlot& s, int i, Profiler* prof);
   halo_fn_t halo_fn_ = nullptr;
   void* halo_user_ = nullptr;
   bool halo_drain_ = true, halo_post_ = false, halo_split_ = false, halo_nyq_aware_ = false;
@@ -413,6 +441,7 @@ class Engine {
   // second work volume: the direct dim0 leg is out of place, work_ and work2_ swap roles after it
   float* work2_ = nullptr;
   cfloat* work2_nyq_ = nullptr;
+  float *work_alloc_ = nullptr, *work2_alloc_ = nullptr;  // what the two work volumes were allocated as
   bool spec_tiled_ = false;
   float* stage_spec_scratch_ = nullptr;  // owned by stage_scratch_
   void wait_staged(int v);

@@ -1311,10 +1311,32 @@ MVN_HD void fx_r2c_post(const RowsParams& P, long r0, cfloat* buf, const cfloat*
   }
 }
 
+// LINES: the half-spectrum is kept in the line layout of the fused middle pass (mvn_mid_fused.hpp),
+// spec[plane][position][row of the plane]: the T rows of a tile are T neighbouring entries of H lines, one
+// 8-byte access per lane, T lanes per line (128 contiguous bytes for 16-row tiles).  Row `r0` of the launch is row
+// P.row_base + r0 of the volume; tiles never straddle planes (T divides the rows of a plane).
 template <int H>
+MVN_HD long fx_lines_base(const RowsParams& P, long r0) {
+  const long R = P.row_base + r0;
+  const long z = R / P.lines_d1;
+  return z * (long)H * P.lines_d1 + (R - z * P.lines_d1);
+}
+
+template <int H, bool LINES = false>
 MVN_HD void fx_r2c_store(const RowsParams& P, long r0, const cfloat* buf, int tid) {
   typedef FxRowsCfg<H> C;
   constexpr int TP = C::TP, NT = C::NT, U = C::U;
+  if constexpr (LINES) {
+    static_assert((C::T * H) % NT == 0, "line layout: whole sweeps");
+    cfloat* dst = P.out_cplx + fx_lines_base<H>(P, r0);
+#pragma unroll
+    for (int u = 0; u < 2 * U; ++u) {
+      const int e = tid + u * NT;
+      const int rho = e % C::T, p = e / C::T;
+      dst[(long)p * P.lines_d1 + rho] = buf[fx_row<C::PAD>(p) * TP + rho];
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
@@ -1327,7 +1349,7 @@ MVN_HD void fx_r2c_store(const RowsParams& P, long r0, const cfloat* buf, int ti
   }
 }
 
-template <int H, typename Ctx>
+template <int H, typename Ctx, bool LINES = false>
 MVN_HD void fx_rows_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& ctx) {
   typedef FxRowsCfg<H> C;
   constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
@@ -1339,7 +1361,7 @@ MVN_HD void fx_rows_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   MVN_PHASE(ctx, (fx_r2c_load_stage0<H>(P, r0, buf, tws, twr, tid)));
   fx_dif<H, T, TP, C::PAD, NT, -1, 1, C::TWT>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
-  MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
+  MVN_PHASE(ctx, (fx_r2c_store<H, LINES>(P, r0, buf, tid)));
 }
 
 // compile-time-mode form of the fused pass's pair epilogue: the kernels are instantiated per
@@ -1351,17 +1373,29 @@ MVN_HD cfloat fx_epilogue_pair_value(const EpilogueParams& e, long i, cfloat z, 
 
 // c2r phase 0: spectral rows -> LDS (position order both sides), plus the epilogue operands of the
 // elements this thread will finish in the last inverse stage, fetched a whole transform ahead
-template <int H, int EPI>
+template <int H, int EPI, bool LINES = false>
 MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, cfloat* twr,
                         FxRowsRegs<H>& r, int tid) {
   typedef FxRowsCfg<H> C;
   constexpr int TP = C::TP, NT = C::NT, U = C::U;
+  if constexpr (LINES) {
+    // two 8-byte entries per register quad: sweep 2 u in .xy, sweep 2 u + 1 in .zw
+    const cfloat* src = P.in_cplx + fx_lines_base<H>(P, r0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e0 = tid + 2 * u * NT, e1 = e0 + NT;
+      const cfloat a = src[(long)(e0 / C::T) * P.lines_d1 + e0 % C::T];
+      const cfloat b = src[(long)(e1 / C::T) * P.lines_d1 + e1 % C::T];
+      r.v[u] = qmake(a.x, a.y, b.x, b.y);
+    }
+  } else {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
     if (!C::EXACT && e >= C::T * C::QR) break;
     const int rho = e / C::QR, kk = e % C::QR;
     r.v[u] = reinterpret_cast<const qfloat*>(P.in_cplx + (r0 + rho) * P.C)[kk];
+  }
   }
   constexpr int mode = EPI;
   const float* pa = mode == MVN_EPI_DIVIDE ? P.epi.view : P.epi.psi;
@@ -1387,6 +1421,15 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
     }
   }
   if (!C::WALK) fx_rows_tables<H>(P, tws, twr, tid);
+  if constexpr (LINES) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e0 = tid + 2 * u * NT, e1 = e0 + NT;
+      buf[fx_row<C::PAD>(e0 / C::T) * TP + e0 % C::T] = cmake(r.v[u].x, r.v[u].y);
+      buf[fx_row<C::PAD>(e1 / C::T) * TP + e1 % C::T] = cmake(r.v[u].z, r.v[u].w);
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = tid + u * NT;
@@ -1473,7 +1516,7 @@ MVN_HD void fx_c2r_stage0_epilogue(const RowsParams& P, long r0, cfloat* buf, co
 // of the pointwise step), writes the half-spectrum of the result in place (UPDATE also writes
 // psi).  The reference runs cufftExecC2R, a pointwise kernel and cufftExecR2C here
 // (inc/gpu_convolve.cuh:140-141 + inc/cuda_kernels.cuh:14-112 + inc/gpu_convolve.cuh:121).
-template <int H, int EPI, typename Ctx>
+template <int H, int EPI, typename Ctx, bool LINES = false>
 MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& ctx) {
   typedef FxRowsCfg<H> C;
   constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
@@ -1482,7 +1525,7 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
   cfloat* buf = lds;
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
-  MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
+  MVN_PHASE(ctx, (fx_c2r_load<H, EPI, LINES>(P, r0, buf, tws, twr, r, tid)));
 #if !(defined(MVN_EXPERIMENTS) && defined(MVN_EXP_SKIP_PREPOST))  // timing experiment (variant builds only, WRONG results): what two LDS round trips cost
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
 #endif
@@ -1492,10 +1535,10 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
 #if !(defined(MVN_EXPERIMENTS) && defined(MVN_EXP_SKIP_PREPOST))
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
 #endif
-  MVN_PHASE(ctx, (fx_r2c_store<H>(P, r0, buf, tid)));
+  MVN_PHASE(ctx, (fx_r2c_store<H, LINES>(P, r0, buf, tid)));
 }
 
-template <int H, int EPI, typename Ctx>
+template <int H, int EPI, typename Ctx, bool LINES = false>
 MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& ctx) {
   typedef FxRowsCfg<H> C;
   constexpr int T = C::T, TP = C::TP, NT = C::NT, NT_ = C::NT;
@@ -1504,7 +1547,7 @@ MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   cfloat* buf = lds;
   cfloat* tws = lds + C::TILE;
   cfloat* twr = tws + fx_twsize(H);
-  MVN_PHASE(ctx, (fx_c2r_load<H, EPI>(P, r0, buf, tws, twr, r, tid)));
+  MVN_PHASE(ctx, (fx_c2r_load<H, EPI, LINES>(P, r0, buf, tws, twr, r, tid)));
   MVN_PHASE(ctx, (fx_c2r_pre<H>(P, r0, buf, twr, tid)));
   fx_dit<H, T, TP, C::PAD, NT, +1, 1, C::TWT>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_c2r_stage0_epilogue<H, false, EPI>(P, r0, buf, tws, r, tid)));
@@ -1512,18 +1555,28 @@ MVN_HD void fx_rows_c2r_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
 
 // One workgroup of a last-axis launch: its single tile, or (FxRowsCfg<H>::WALK) the tables once
 // and then tiles block, block + nblocks, ...  KIND 0: r2c, 1: c2r, 2: c2r + pointwise + r2c.
-template <int H, int KIND, int EPI, typename Ctx>
+template <int H, int KIND, int EPI, typename Ctx, bool LINES = false>
 MVN_HD void fx_rows_tile(const RowsParams& P, long tile, cfloat* lds, Ctx& ctx) {
   if constexpr (KIND == 0)
-    fx_rows_r2c_body<H>(P, tile, lds, ctx);
+    fx_rows_r2c_body<H, Ctx, LINES>(P, tile, lds, ctx);
   else if constexpr (KIND == 1)
-    fx_rows_c2r_body<H, EPI>(P, tile, lds, ctx);
+    fx_rows_c2r_body<H, EPI, Ctx, LINES>(P, tile, lds, ctx);
   else
-    fx_rows_c2r_r2c_body<H, EPI>(P, tile, lds, ctx);
+    fx_rows_c2r_r2c_body<H, EPI, Ctx, LINES>(P, tile, lds, ctx);
 }
 
-template <int H, int KIND, int EPI, typename Ctx>
+// which last-axis lengths have the line-layout forms (one 16-row tile per workgroup)
+template <int H>
+constexpr bool fx_rows_lines_ok() {
+  return H == 256 && !FxRowsCfg<H>::WALK && FxRowsCfg<H>::T == 16 && FxRowsCfg<H>::EXACT;
+}
+
+template <int H, int KIND, int EPI, typename Ctx, bool LINES = false>
 MVN_HD void fx_rows_run(const RowsParams& P, long block, long nblocks, cfloat* lds, Ctx& ctx) {
+  if constexpr (LINES) {
+    fx_rows_tile<H, KIND, EPI, Ctx, true>(P, block, lds, ctx);
+    return;
+  }
   typedef FxRowsCfg<H> C;
   if constexpr (C::WALK) {
     constexpr int NT_ = C::NT;

@@ -94,34 +94,53 @@ __global__ void __launch_bounds__(512) k_strided(const StridedParams p) {
 }
 
 // ---- compile-time specialised kernels for power-of-two lengths (mvn_fixed.hpp) ----------------
-template <int H>
+// (LINES: the half-spectrum side in the line layout of the fused middle pass, mvn_fixed.hpp fx_lines_base)
+template <int H, bool LINES = false>
 __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_r2c(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
-  FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
+  typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+  Ctx ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_run<H, 0, MVN_EPI_STORE>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_run<H, 0, MVN_EPI_STORE, Ctx, LINES>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
-template <int H, int EPI>
+template <int H, int EPI, bool LINES = false>
 __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r(const RowsParams p0) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   RowsParams p = p0;
   mvn_arm_poison(p.epi);
-  FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
+  typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+  Ctx ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_run<H, 1, EPI>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_run<H, 1, EPI, Ctx, LINES>(p, (long)blockIdx.x, (long)gridDim.x, (cfloat*)mvn_smem, ctx);
 }
 
 // (The divide form needs 93 VGPRs, just above the 84 that would let three 512-thread workgroups
 // share a CU; forcing it there with a waves-per-SIMD bound spilled 56 bytes and gained nothing.)
-template <int H, int EPI>
+template <int H, int EPI, bool LINES = false>
 __global__ void __launch_bounds__(FxRowsCfg<H>::NT) kx_rows_c2r_r2c(const RowsParams p0) {
   extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
   RowsParams p = p0;
   mvn_arm_poison(p.epi);
-  FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> ctx;
+  typedef FxCtx<FxRowsRegs<H>, FxRowsCfg<H>::NT> Ctx;
+  Ctx ctx;
   ctx.tid = (int)threadIdx.x;
-  fx_rows_run<H, 2, EPI>(p, (long)MVN_PROBE_TILE(blockIdx.x), (long)gridDim.x, (cfloat*)mvn_smem, ctx);
+  fx_rows_run<H, 2, EPI, Ctx, LINES>(p, (long)MVN_PROBE_TILE(blockIdx.x), (long)gridDim.x, (cfloat*)mvn_smem, ctx);
+}
+
+// the fused middle pass (mvn_mid_fused.hpp): one column (piece) per workgroup
+template <int K>
+__global__ void __launch_bounds__(MF_NT) kf_mid(const MidFusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<MfRegs<K>, MF_NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  mf_body<K>(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
+}
+__global__ void __launch_bounds__(MF_NT) kf_mid_taps(const MidFusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char mvn_smem[];
+  FxCtx<MfRegs<1>, MF_NT> ctx;
+  ctx.tid = (int)threadIdx.x;
+  mf_taps_body(p, (long)blockIdx.x, (cfloat*)mvn_smem, ctx);
 }
 
 // last-axis passes for d2 = 512 in which a row never leaves its half-wave (mvn_wave_rows.hpp): no
@@ -566,7 +585,7 @@ static bool wave_rows_enabled(const RowsParams& p, int kind_bit) {
     const char* e = std::getenv("MVN_WAVE_ROWS_MASK");
     return e && *e ? std::atoi(e) : 28;
   }();
-  return !off && (mask & kind_bit) && p.fixed && p.h == WrCfg::H && p.C == WrCfg::H;
+  return !off && (mask & kind_bit) && p.fixed && !p.lines && p.h == WrCfg::H && p.C == WrCfg::H;
 }
 
 // `mult_default` workgroups per resident slot: short-lived workgroups that the dispatcher keeps
@@ -629,9 +648,21 @@ static void check_aligned16(const void* p, const char* what) {
   if (((size_t)p) & 15) throw std::invalid_argument(std::string("mvn: fixed kernels need 16-byte aligned ") + what);
 }
 
+// line-layout forms of the fixed last-axis kernels (H = 256: d2 = 512)
+static void check_lines(const RowsParams& p, long nblocks) {
+  constexpr int H = 256;
+  if (!fx_rows_lines_ok<H>() || !p.fixed || p.h != H || p.C != H || !p.nyq_packed || p.lines_d1 < 1 ||
+      p.lines_d1 % FxRowsCfg<H>::T || p.row_base % FxRowsCfg<H>::T || p.rows != nblocks * FxRowsCfg<H>::T)
+    throw std::invalid_argument("mvn: line-layout last-axis pass outside its range");
+}
+
 void launch_rows_r2c(const RowsParams& p, bool even, long nblocks, int nthreads, size_t lds_bytes,
                      stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (p.lines) {
+    check_lines(p, nblocks);
+    return launch_pass(kx_rows_r2c<256, true>, p, nblocks, nthreads, lds_bytes, s);
+  }
   if (p.fixed) {
     check_aligned16(p.in_real, "input");
     check_aligned16(p.out_cplx, "output");
@@ -653,6 +684,15 @@ void launch_rows_r2c(const RowsParams& p, bool even, long nblocks, int nthreads,
 void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads, size_t lds_bytes,
                      stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (p.lines) {
+    check_lines(p, nblocks);
+    switch (p.epi.mode) {
+      case MVN_EPI_DIVIDE: return launch_pass(kx_rows_c2r<256, MVN_EPI_DIVIDE, true>, p, nblocks, nthreads, lds_bytes, s);
+      case MVN_EPI_UPDATE: return launch_pass(kx_rows_c2r<256, MVN_EPI_UPDATE, true>, p, nblocks, nthreads, lds_bytes, s);
+      case MVN_EPI_DELTA: return launch_pass(kx_rows_c2r<256, MVN_EPI_DELTA, true>, p, nblocks, nthreads, lds_bytes, s);
+      default: return launch_pass(kx_rows_c2r<256, MVN_EPI_STORE, true>, p, nblocks, nthreads, lds_bytes, s);
+    }
+  }
   if (p.fixed) {
     check_aligned16(p.in_cplx, "input");
     check_aligned16(p.out_real, "output");
@@ -689,6 +729,14 @@ void launch_rows_c2r(const RowsParams& p, bool even, long nblocks, int nthreads,
 void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t lds_bytes,
                          stream_t s) {
   check_launch(nblocks, nthreads, lds_bytes);
+  if (p.lines) {
+    check_lines(p, nblocks);
+    switch (p.epi.mode) {
+      case MVN_EPI_DIVIDE: return launch_pass(kx_rows_c2r_r2c<256, MVN_EPI_DIVIDE, true>, p, nblocks, nthreads, lds_bytes, s);
+      case MVN_EPI_UPDATE: return launch_pass(kx_rows_c2r_r2c<256, MVN_EPI_UPDATE, true>, p, nblocks, nthreads, lds_bytes, s);
+      default: return launch_pass(kx_rows_c2r_r2c<256, MVN_EPI_STORE, true>, p, nblocks, nthreads, lds_bytes, s);
+    }
+  }
   if (!p.fixed) {
     MVN_DISPATCH_T(p.T, (k_rows_c2r_r2c<TT>));
     return;
@@ -719,6 +767,8 @@ void launch_rows_c2r_r2c(const RowsParams& p, long nblocks, int nthreads, size_t
 
 static std::atomic<long> g_split_launches{0};
 long split_launch_count() { return g_split_launches.load(); }
+static std::atomic<long> g_mid_fused_launches{0};
+long mid_fused_launch_count() { return g_mid_fused_launches.load(); }
 
 // long lines: 16-column tiles through the split-window body when the columns divide (the plan's
 // geometry is for the 8-column kernel); MVN_NO_SPLIT=1 keeps the 8-column kernel
@@ -822,6 +872,27 @@ void launch_dim0_direct(const Dim0DirectParams& p, stream_t s) {
     default: throw std::invalid_argument("mvn: no direct dim0 kernel for this tap count");
   }
   HIP_CHECK(hipGetLastError());
+}
+
+// the fused middle pass: instantiated for odd tap counts up to 31 (33 taps would need 40 window slots: beyond the
+// registers of two waves per SIMD)
+#define MVN_MF_TAP_COUNTS(X) X(1) X(3) X(5) X(7) X(9) X(11) X(13) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31)
+void launch_mid_fused(const MidFusedParams& p, stream_t s) {
+  mf_check(p);
+  const long nblocks = mf_blocks(p);
+  if (nblocks < 1 || nblocks > 0x7fffffffL) throw std::invalid_argument("mvn: grid size out of range");
+  const size_t lds = sizeof(cfloat) * (size_t)MF_LDS_CFLOATS;
+  if (p.mode == MF_TAPS) {
+    launch_pass(kf_mid_taps, p, nblocks, MF_NT, lds, s);
+    return;
+  }
+  ++g_mid_fused_launches;
+  switch (mvn_dim0_taps_template(p.k)) {
+#define X(K) case K: launch_pass(kf_mid<K>, p, nblocks, MF_NT, lds, s); break;
+    MVN_MF_TAP_COUNTS(X)
+#undef X
+    default: throw std::invalid_argument("mvn: no fused middle pass for this tap count");
+  }
 }
 
 static unsigned flat_grid(size_t n, int block) {

@@ -1,0 +1,525 @@
+// mvn_mid_fused.hpp -- the three middle passes of a convolution as ONE pass over the volume (round 4).
+//
+// The reference convolves by 3-D FFT x PSF spectrum x inverse 3-D FFT (inc/gpu_convolve.cuh:113-142,
+// inc/cpu_convolve.h:217-291).  Between the two last-axis passes this library ran three passes over the
+// half-spectrum: dim1 forward, the dim0 leg as a direct K-tap convolution (mvn_dim0_direct.hpp), dim1 inverse -
+// 6 volumes of HBM traffic per convolution, 0.62 ms at 512^3, none of them above 0.6 of the HBM roofline and
+// none with anything left to tune (profiles/r04_dim0_direct.md).  The three are one pass here: 2 volumes.
+//
+// What makes that possible is the layout of the half-spectrum BETWEEN the last-axis passes ("line layout"):
+//     spec[z][c][y]      z < d0 planes,  c < H columns (last-axis positions),  y < N1 rows of the plane
+// i.e. the lines along dim1 are contiguous (the row-major layout [z][y][c] keeps them C bins apart).  A workgroup
+// takes ONE column c and walks along dim0: a line (z, c, .) of N1 = 512 bins comes in, is transformed along dim1
+// (one line per wave, 8 bins per lane, radix 8 x 8 x 8 with two wave-private LDS exchanges), every bin goes through
+// its K-tap filter along dim0 - the filter state (K taps, K inputs) lives in the registers of the ONE work item
+// that owns the bin for the whole walk -, the line is transformed back and stored.  31 lines of a column are the
+// window of the direct convolution: 124 KB, which is what the registers of one CU hold beside the code's own
+// needs - so a column is a CU's work (256 columns, 256 CUs at d2 = 512), and the last-axis passes write / read
+// the line layout (16 rows of a tile are 128 contiguous bytes of 16 lines; mvn_fixed.hpp, FxRowsCfg<H>::LINES).
+//
+// Bins of a line are kept in the order the forward transform leaves them in a wave's registers
+//     q = 64 j + 8 k + a   <->   frequency f = k + 8 a + 64 j        (k, a, j < 8)
+// the taps are stored in the same order (they go through the same forward code, MF_TAPS), and the inverse
+// transform undoes it: no permutation anywhere.
+//
+// Pipeline of a workgroup (8 waves, batches of 8 lines = 8 consecutive planes, one line per wave), iteration i:
+//     wave w:  inverse transform + store of line w of batch i - 1      (buffer B[(i + 1) & 1], line w)
+//              forward transform of line w of batch i + 1 -> LDS       (same buffer, same line: wave-private)
+//              global loads of line w of batch i + 2 -> registers
+//     all:     filter step on the 8 lines of batch i, in place          (buffer B[i & 1]; work item q <-> bin q)
+//     ONE workgroup barrier
+// The window is indexed with compile-time register numbers: KW = K rounded up to a multiple of 8 slots, the
+// filter code exists KW / 8 times (batch i uses variant i mod KW / 8), selected by a workgroup-uniform branch.
+#pragma once
+
+#include <stdexcept>
+
+#include "mvn_dim0_direct.hpp"
+#include "mvn_wave_rows.hpp"
+
+// A wave phase here ends where lanes of ONE wave hand data to each other through the LDS: what has to be kept is
+// the order of the wave's LDS instructions (they execute in order), nothing else - in particular the global loads
+// requested ahead must stay in flight across it (the all-address-space fence of MVN_WPHASE waits for them).
+#ifndef MF_LOCAL_FENCE
+#define MF_LOCAL_FENCE 1
+#endif
+#if MF_LOCAL_FENCE
+#define MF_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local")
+#else
+#define MF_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#endif
+#ifndef MF_SPLIT_ORDER
+#define MF_SPLIT_ORDER 1
+#endif
+#ifndef MF_TW_REGS
+#define MF_TW_REGS 0
+#endif
+#if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
+#define MF_WPHASE(ctx, ...)                                         \
+  {                                                                 \
+    const int tid = (ctx).tid;                                      \
+    auto& r = (ctx).regs;                                           \
+    (void)r;                                                        \
+    __VA_ARGS__;                                                    \
+  }                                                                 \
+  MF_FENCE();                                                       \
+  __builtin_amdgcn_wave_barrier();
+#else
+#define MF_WPHASE(ctx, ...) MVN_PHASE(ctx, __VA_ARGS__)
+#endif
+
+#define MF_N1 512         // line length (dim1 extent)
+#define MF_NT 512         // work items: one per bin of a line
+#define MF_LINES 8        // lines per batch: one per wave
+#define MF_PITCH 576      // cfloats per LDS line: 8 blocks of 64 + 8 spare (the exchanges' bank spreading)
+#define MF_BUF (MF_LINES * MF_PITCH)
+#define MF_TWL 512          // the lanes' twiddles in the LDS: stage 0 [m][l] (m = 1..7, 64 lanes), stage 1 [m][l & 7] behind them
+#define MF_LDS_CFLOATS (2 * MF_BUF + MF_TWL)
+
+struct MidFusedParams {
+  const cfloat* in;    // [d0][H][MF_N1]
+  cfloat* out;         // same layout; must not alias `in` (pieces read planes their neighbours write)
+  const cfloat* taps;  // [kd][H][MF_N1], bins in the kernel's own order: tap j lives in plane (j - h + kd) % kd (the PSF
+                       // scattered cyclically around plane 0, as for Dim0DirectParams)
+  int kd;              // planes of the tap array, >= k
+  const cfloat* tw;    // exp(-2 pi i j / MF_N1), j < MF_N1 (AxisPlan::tw of the dim1 axis)
+  int d0, H;
+  int k, h;            // taps, k / 2;   out[z] = sum_j tap[j] in[(z + h - j) mod d0]
+  int seg;             // output planes per piece; 0: whole columns (one workgroup per column)
+  int mode;            // MF_CONV, or MF_TAPS: forward transform only, bins stored in the kernel's order (PSF prep)
+  int packed;          // column 0 holds DC + i Nyquist of every row (RowsParams::nyq_packed), in the volume and in the
+                       // taps: see "packed DC column" below
+  // non-finite inputs: as Dim0DirectParams
+  unsigned* poison;
+  unsigned poison_epoch;
+};
+enum { MF_CONV = 0, MF_TAPS = 1 };
+
+constexpr int mf_slots(int K) { return (K + 7) / 8 * 8; }
+
+template <int K>
+struct MfRegs {
+  cfloat tap[K];
+  cfloat w[mf_slots(K)];
+  cfloat xr[8];   // the wave's line of the batch after next, as loaded (element l + 64 m in xr[m])
+  cfloat t[8];    // a transform stage's values between its reads and its writes
+#if MF_TW_REGS
+  cfloat tw0[8], tw1[8];  // the lane's twiddles (A/B: registers instead of the LDS table)
+#endif
+  cfloat bad;
+  int pairwise;   // packed DC column, bins 0 and 256: two REAL streams with two real taps (see below)
+};
+
+inline long mf_pieces(const MidFusedParams& P) { return P.seg > 0 ? (P.d0 + P.seg - 1) / P.seg : 1; }
+inline long mf_blocks(const MidFusedParams& P) { return P.mode == MF_TAPS ? (long)P.H * ((P.d0 + MF_LINES - 1) / MF_LINES) : (long)P.H * mf_pieces(P); }
+
+// the job of workgroup `block`: column c, first output plane z0, output planes nout
+MVN_HD void mf_job(const MidFusedParams& P, long block, int& c, int& z0, int& nout) {
+  const long piece = block / P.H;
+  c = (int)(block - piece * P.H);
+  if (P.seg > 0) {
+    z0 = (int)(piece * P.seg);
+    nout = P.d0 - z0 < P.seg ? P.d0 - z0 : P.seg;
+  } else {
+    z0 = 0;
+    nout = P.d0;
+  }
+}
+
+MVN_HD int mf_tap_plane(const MidFusedParams& P, int j) {
+  const int p = j - P.h;
+  return p < 0 ? p + P.kd : p;
+}
+
+inline void mf_check(const MidFusedParams& P) {
+  const bool taps_mode = P.mode == MF_TAPS;
+  if (!P.in || !P.out || !P.tw || P.d0 < 1 || P.H < 1 || (long)P.d0 * P.H * MF_N1 >= (1L << 31) * 4 || P.seg < 0)
+    throw std::invalid_argument("mvn: fused middle pass: bad arguments");
+  if (!taps_mode && (!P.taps || P.in == P.out || P.k < 1 || mvn_dim0_taps_template(P.k) > 31 || P.h != P.k / 2 || P.kd < P.k))
+    throw std::invalid_argument("mvn: fused middle pass called outside its range");
+}
+
+// plane that step n of the walk reads: the walk starts h planes before its first output (cyclically)
+MVN_HD int mf_in_plane(const MidFusedParams& P, int z0, int n) {
+  int z = (z0 - P.h + n) % P.d0;
+  return z < 0 ? z + P.d0 : z;
+}
+
+template <int K>
+MVN_HD void mf_fetch(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int batch, int nsteps, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const int n = batch * MF_LINES + wv;
+  if (n >= nsteps) return;
+  const cfloat* src = P.in + ((long)mf_in_plane(P, z0, n) * P.H + c) * MF_N1 + l;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.xr[m] = src[64 * m];
+}
+
+template <int K>
+MVN_HD void mf_setup(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int nsteps, int tid) {
+  r.bad = cmake(0.f, 0.f);
+  r.pairwise = 0;
+#if MF_TW_REGS
+#pragma unroll
+  for (int m = 1; m < 8; ++m) {
+    r.tw0[m] = P.tw[(tid & 63) * m];
+    r.tw1[m] = P.tw[8 * (tid & 7) * m];
+  }
+#endif
+#pragma unroll
+  for (int j = 0; j < K; ++j) r.tap[j] = j < P.k ? P.taps[((long)mf_tap_plane(P, j) * P.H + c) * MF_N1 + tid] : cmake(0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < mf_slots(K); ++s) r.w[s] = cmake(0.f, 0.f);
+  mf_fetch<K>(P, r, c, z0, 0, nsteps, tid);
+}
+
+// The lanes' twiddles live in the LDS (they would be 28 registers next to the filter's 126): stage 0, lane l:
+// exp(-2 pi i l m / 512) at [m - 1][l]; stage 1: exp(-2 pi i (l & 7) m / 64) at 448 + [m - 1][l & 7].
+MVN_HD void mf_build_twiddles(const MidFusedParams& P, cfloat* twl, int tid) {
+  if (tid < 448) {
+    const int m = tid / 64 + 1, l = tid & 63;
+    twl[tid] = P.tw[l * m];
+  } else if (tid < 448 + 56) {
+    const int e = tid - 448, m = e / 8 + 1, j = e & 7;
+    twl[tid] = P.tw[8 * j * m];
+  }
+}
+#if MF_TW_REGS
+#define mf_tw0(twl, l, m) (r.tw0[m])
+#define mf_tw1(twl, l, m) (r.tw1[m])
+#else
+MVN_HD cfloat mf_tw0(const cfloat* twl, int l, int m) { return twl[(m - 1) * 64 + l]; }
+MVN_HD cfloat mf_tw1(const cfloat* twl, int l, int m) { return twl[448 + (m - 1) * 8 + (l & 7)]; }
+#endif
+
+// ---- forward transform of a wave's line: registers -> LDS line, bins in the order q = 64 j + 8 k + a ----
+template <int K>
+MVN_HD void mf_fwd0(MfRegs<K>& r, cfloat* buf, const cfloat* twl, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* line = buf + wv * MF_PITCH;
+  cfloat a[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a[m] = r.xr[m];
+  dftR<8, -1>(a);
+#pragma unroll
+  for (int m = 1; m < 8; ++m) a[m] = cmul(a[m], mf_tw0(twl, l, m));
+#pragma unroll
+  for (int m = 0; m < 8; ++m) line[72 * m + l] = a[m];  // sub-line m (frequencies m + 8 .), element l
+}
+// Every exchange stage is a pair: `_a` reads the lane's inputs from the line and computes into r.t, `_b` writes
+// r.t to the places the NEXT stage reads.  On the device the two run back to back (a wave's LDS instructions
+// execute in order: every lane has read before any lane writes); the test-only host emulation, which runs a phase
+// lane after lane, puts a phase boundary between them.
+template <int K>
+MVN_HD void mf_fwd1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);  // sub-line l >> 3, elements (l & 7) + 8 a
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.t[m] = p[8 * m];
+  dftR<8, -1>(r.t);
+#pragma unroll
+  for (int m = 1; m < 8; ++m) r.t[m] = cmul(r.t[m], mf_tw1(twl, l, m));
+}
+template <int K>
+MVN_HD void mf_fwd1_b(const MfRegs<K>& r, cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) p[9 * m] = r.t[m];  // [a' = m][j = l & 7] with pitch 9: both sides conflict-free
+}
+template <int K>
+MVN_HD void mf_fwd2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + 9 * (l & 7);  // lane (k, a) = (l >> 3, l & 7): its 8 values j
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.t[m] = p[m];
+  dftR<8, -1>(r.t);
+}
+template <int K>
+MVN_HD void mf_fwd2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* line = buf + wv * MF_PITCH;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) line[64 * m + l] = r.t[m];  // bin q = 64 j + l
+}
+
+// ---- inverse transform of a wave's line: LDS line (bins in order q) -> registers in natural order ----
+template <int K>
+MVN_HD void mf_inv2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* line = buf + wv * MF_PITCH;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.t[m] = line[64 * m + l];
+  dftR<8, +1>(r.t);
+}
+template <int K>
+MVN_HD void mf_inv2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + 9 * (l & 7);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) p[m] = r.t[m];
+}
+template <int K>
+MVN_HD void mf_inv1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.t[m] = p[9 * m];
+#pragma unroll
+  for (int m = 1; m < 8; ++m) r.t[m] = cmulc(r.t[m], mf_tw1(twl, l, m));
+  dftR<8, +1>(r.t);
+}
+template <int K>
+MVN_HD void mf_inv1_b(const MfRegs<K>& r, cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) p[8 * m] = r.t[m];
+}
+template <int K>
+MVN_HD void mf_inv0_store(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, cfloat* dst, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* line = buf + wv * MF_PITCH;
+  cfloat a[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a[m] = line[72 * m + l];
+#pragma unroll
+  for (int m = 1; m < 8; ++m) a[m] = cmulc(a[m], mf_tw0(twl, l, m));
+  dftR<8, +1>(a);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) dst[l + 64 * m] = a[m];
+}
+
+// line w of batch `batch` is output m = 8 batch + w - (K - 1) of the walk (the first K - 1 steps only fill the window)
+template <int K>
+MVN_HD void mf_store_line(const MidFusedParams& P, MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int c, int z0,
+                          int nout, int batch, int tid) {
+  const int m = batch * MF_LINES + (tid >> 6) - (K - 1);
+  if (m < 0 || m >= nout) return;
+  int z = z0 + m;
+  z = z >= P.d0 ? z - P.d0 : z;
+  mf_inv0_store<K>(r, buf, twl, P.out + ((long)z * P.H + c) * MF_N1, tid);
+}
+
+// ---- the filter step on the 8 lines of a batch, in place: work item q <-> bin q of every line ----
+// U = (batch mod KW / 8): step n = 8 batch + c fills slot 8 U + c; tap j multiplies the input of step n - j.
+// FILL: the first K - 1 steps of a walk only fill the window.
+template <int K, int U, bool FILL>
+MVN_HD void mf_filter(MfRegs<K>& r, cfloat* buf, int tid) {
+  constexpr int KW = mf_slots(K);
+#pragma unroll
+  for (int c = 0; c < MF_LINES; ++c) {
+    cfloat* p = buf + c * MF_PITCH + tid;
+    const cfloat x = *p;
+    constexpr int S0 = 8 * U;
+    r.w[S0 + c] = x;
+    if (FILL) continue;
+    r.bad = mvn_dim0_track(r.bad, x);
+    cfloat s1, s2;
+    mvn_cmul2(s1, s2, r.w[(S0 + c + KW) % KW], r.tap[0]);
+    if constexpr (K > 1) {
+      cfloat t1, t2;
+      mvn_cmul2(t1, t2, r.w[(S0 + c - 1 + KW) % KW], r.tap[1]);
+#pragma unroll
+      for (int j = 2; j + 1 < K; j += 2) {
+        mvn_cmac2(s1, s2, r.w[(S0 + c - j + 2 * KW) % KW], r.tap[j]);
+        mvn_cmac2(t1, t2, r.w[(S0 + c - j - 1 + 2 * KW) % KW], r.tap[j + 1]);
+      }
+      if (K % 2) mvn_cmac2(s1, s2, r.w[(S0 + c - (K - 1) + 2 * KW) % KW], r.tap[K - 1]);
+      s1 = cadd(s1, t1);
+      s2 = cadd(s2, t2);
+    }
+    const cfloat o = cadd_i<+1>(s1, s2);
+    *p = r.pairwise ? cmake(s1.x, s2.y) : o;
+    MVN_SCHED_FENCE();  // one line at a time: the scheduler would otherwise start all eight at once
+  }
+}
+template <int K, int U>
+MVN_HD void mf_filter_dispatch(MfRegs<K>& r, cfloat* buf, int u, bool fill, int tid) {
+  if (u == U) {
+    if (fill)
+      mf_filter<K, U, true>(r, buf, tid);
+    else
+      mf_filter<K, U, false>(r, buf, tid);
+    return;
+  }
+  if constexpr (U + 1 < mf_slots(K) / 8) mf_filter_dispatch<K, U + 1>(r, buf, u, fill, tid);
+}
+
+// (a FILL batch still tracks nothing: the planes it reads are tracked by the piece that outputs them.  A step that
+// outputs tracks its newest input in[z + h]: over the pieces of a column every plane exactly once.)
+
+// ---------------------------------------------------------------------------------------------------------
+// Packed DC column.  Column 0 of the volume holds P[y] = x0[y] + i xh[y]: the DC and the Nyquist bin of row y,
+// both real (RowsParams::nyq_packed); after the transform along the line P[f] = X0[f] + i XH[f] with X0, XH
+// Hermitian in f.  The two need different taps (T0, TH; the taps' own column 0 holds T0 + i TH the same way).
+// The workgroup of column 0 therefore separates them behind the forward transform,
+//     X0[f] = (P[f] + conj P[-f]) / 2,    XH[f] = -i (P[f] - conj P[-f]) / 2,
+// lets the work item of bin f (0 < f < 256) filter X0[f] with T0[f] and the work item of bin -f filter XH[f] with
+// TH[f], and puts them together again in front of the inverse transform:
+//     R[f] = R0[f] + i RH[f],    R[-f] = conj R0[f] + i conj RH[f].
+// f = 0 and f = 256 pair with themselves: X0 and XH are real there, as are the taps, so P[f] IS the pair
+// (X0[f], XH[f]) and the packed tap IS (T0[f], TH[f]); the work items of those two bins filter the two halves
+// separately - with the two chains every work item keeps anyway (s1 runs on the real parts, s2 on the imaginary
+// parts: the result is (s1.x, s2.y) instead of the complex combination).
+// ---------------------------------------------------------------------------------------------------------
+MVN_HD int mf_bin_of(int f) { return 64 * (f >> 6) + 8 * (f & 7) + ((f >> 3) & 7); }
+MVN_HD int mf_freq_of(int q) { return ((q >> 3) & 7) + 8 * (q & 7) + 64 * (q >> 6); }
+// Hermitian parts of a pair: a = P[f], b = P[-f]  ->  X0[f], XH[f]
+MVN_HD cfloat mf_herm0(cfloat a, cfloat b) { return cmake(0.5f * (a.x + b.x), 0.5f * (a.y - b.y)); }
+MVN_HD cfloat mf_hermh(cfloat a, cfloat b) { return cmake(0.5f * (a.y + b.y), 0.5f * (b.x - a.x)); }
+
+template <int K>
+MVN_HD void mf_setup_dc(const MidFusedParams& P, MfRegs<K>& r, int tid) {
+  const int f = mf_freq_of(tid), fm = (MF_N1 - f) & (MF_N1 - 1), qm = mf_bin_of(fm);
+  r.pairwise = f == fm;
+  const cfloat* tp = P.taps + qm;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const cfloat a = r.tap[j], b = j < P.k ? tp[(long)mf_tap_plane(P, j) * P.H * MF_N1] : cmake(0.f, 0.f);
+    // bins 1 .. 255 filter X0 with T0[f]; bins 257 .. 511 filter XH[-f] with TH[-f] (the pair seen from the other side)
+    r.tap[j] = f == fm ? a : (f < MF_N1 / 2 ? mf_herm0(a, b) : mf_hermh(b, a));
+  }
+}
+
+// behind the forward transform of the wave's line: lane l separates the pairs f = l + 64 m (in place: a pair is
+// touched by one lane only)
+MVN_HD void mf_dc_unpack(cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* line = buf + wv * MF_PITCH;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int f = l + 64 * m;
+    if (f == 0) continue;
+    const int q1 = mf_bin_of(f), q2 = mf_bin_of(MF_N1 - f);
+    const cfloat a = line[q1], b = line[q2];
+    line[q1] = mf_herm0(a, b);
+    line[q2] = mf_hermh(a, b);
+  }
+}
+MVN_HD void mf_dc_repack(cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* line = buf + wv * MF_PITCH;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int f = l + 64 * m;
+    if (f == 0) continue;
+    const int q1 = mf_bin_of(f), q2 = mf_bin_of(MF_N1 - f);
+    const cfloat a = line[q1], b = line[q2];  // R0[f], RH[f]
+    line[q1] = cmake(a.x - b.y, a.y + b.x);   // R0 + i RH
+    line[q2] = cmake(a.x + b.y, b.x - a.y);   // conj R0 + i conj RH
+  }
+}
+
+// the transforms of an iteration: line w of batch i - 1 back and out, line w of batch i + 1 in
+template <int K, typename Ctx>
+MVN_HD void mf_transforms(const MidFusedParams& P, cfloat* oth, const cfloat* twl, int i, int nb, int c, int z0, int nout,
+                          int nsteps, bool dc, Ctx& ctx) {
+  constexpr int NT_ = MF_NT;
+  (void)NT_;
+  if (i >= 1) {
+    if (dc) {
+      MF_WPHASE(ctx, (mf_dc_repack(oth, tid)));
+    }
+    MF_WPHASE(ctx, (mf_inv2_a<K>(r, oth, tid)));
+    MF_WPHASE(ctx, (mf_inv2_b<K>(r, oth, tid)));
+    MF_WPHASE(ctx, (mf_inv1_a<K>(r, oth, twl, tid)));
+    MF_WPHASE(ctx, (mf_inv1_b<K>(r, oth, tid)));
+    MF_WPHASE(ctx, (mf_store_line<K>(P, r, oth, twl, c, z0, nout, i - 1, tid)));
+  }
+  if (i + 1 < nb) {
+    MF_WPHASE(ctx, (mf_fwd0<K>(r, oth, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
+    MF_WPHASE(ctx, (mf_fwd1_a<K>(r, oth, twl, tid)));
+    MF_WPHASE(ctx, (mf_fwd1_b<K>(r, oth, tid)));
+    MF_WPHASE(ctx, (mf_fwd2_a<K>(r, oth, tid)));
+    MF_WPHASE(ctx, (mf_fwd2_b<K>(r, oth, tid)));
+    if (dc) {
+      MF_WPHASE(ctx, (mf_dc_unpack(oth, tid)));
+    }
+  }
+}
+
+template <int K>
+MVN_HD void mf_report(const MidFusedParams& P, const MfRegs<K>& r) {
+  if ((r.bad.x != 0.f || r.bad.y != 0.f) && P.poison) *P.poison = P.poison_epoch;  // (NaN != 0)
+}
+
+template <int K, typename Ctx>
+MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) {
+  constexpr int NT_ = MF_NT;
+  (void)NT_;
+  int c, z0, nout;
+  mf_job(P, block, c, z0, nout);
+  const int nsteps = nout + K - 1;
+  const int nb = (nsteps + MF_LINES - 1) / MF_LINES;
+  const bool dc = P.packed && c == 0;
+  cfloat* twl = lds + 2 * MF_BUF;
+  MVN_PHASE_NOSYNC(ctx, (mf_setup<K>(P, r, c, z0, nsteps, tid), mf_build_twiddles(P, twl, tid)));
+  if (dc) {
+    MVN_PHASE_NOSYNC(ctx, (mf_setup_dc<K>(P, r, tid)));
+  }
+  MVN_PHASE(ctx, (void)0);
+  // Waves 4 .. 7 run the filter step first and the transforms second, waves 0 .. 3 the other way round (the two
+  // work on different buffers): a SIMD's two waves - w and w + 4 - are then in different kinds of code, one in the
+  // filter's multiply-adds while the other waits for its LDS exchanges.  In step, both wait and then both multiply.
+#if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
+  const int filter_first = MF_SPLIT_ORDER ? mvn_uniform((ctx.tid >> 8) & 1) : 0;
+#else
+  const int filter_first = 0;
+#endif
+  for (int i = -1; i <= nb; ++i) {
+    cfloat* cur = lds + (i & 1) * MF_BUF;
+    cfloat* oth = lds + ((i + 1) & 1) * MF_BUF;
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if ((pass == 0) != (filter_first != 0)) {
+        mf_transforms<K>(P, oth, twl, i, nb, c, z0, nout, nsteps, dc, ctx);
+      } else if (i >= 0 && i < nb) {
+        const bool fill = i * MF_LINES + MF_LINES - 1 < K - 1;
+        MF_WPHASE(ctx, (mf_filter_dispatch<K, 0>(r, cur, i % (mf_slots(K) / 8), fill, tid)));
+      }
+    }
+    MVN_PHASE(ctx, (void)0);
+  }
+  MVN_PHASE_NOSYNC(ctx, (mf_report<K>(P, r)));
+}
+
+// PSF preparation: lines [z][c][.] of a small stack (the PSF's planes after the last-axis pass) -> forward
+// transform along dim1, bins stored in the order the filter keeps them.  One batch of 8 planes of one column per
+// workgroup.
+MVN_HD void mf_taps_load(const MidFusedParams& P, MfRegs<1>& r, long batch, int c, int tid) {
+  const int l = tid & 63, z = (int)batch * MF_LINES + (tid >> 6);
+#if MF_TW_REGS
+#pragma unroll
+  for (int m = 1; m < 8; ++m) {
+    r.tw0[m] = P.tw[l * m];
+    r.tw1[m] = P.tw[8 * (l & 7) * m];
+  }
+#endif
+  if (z >= P.d0) return;
+  const cfloat* src = P.in + ((long)z * P.H + c) * MF_N1 + l;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.xr[m] = src[64 * m];
+}
+MVN_HD void mf_taps_store(const MidFusedParams& P, const cfloat* lds, long batch, int c, int tid) {
+  const int l = tid & 63, wv = tid >> 6, z = (int)batch * MF_LINES + wv;
+  if (z >= P.d0) return;
+  cfloat* dst = P.out + ((long)z * P.H + c) * MF_N1 + l;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) dst[64 * m] = lds[wv * MF_PITCH + 64 * m + l];
+}
+template <typename Ctx>
+MVN_HD void mf_taps_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) {
+  constexpr int NT_ = MF_NT;
+  (void)NT_;
+  const long batch = block / P.H;
+  const int c = (int)(block - batch * P.H);
+  cfloat* twl = lds + 2 * MF_BUF;
+  MVN_PHASE(ctx, (mf_taps_load(P, r, batch, c, tid), mf_build_twiddles(P, twl, tid)));
+  MF_WPHASE(ctx, (mf_fwd0<1>(r, lds, twl, tid)));
+  MF_WPHASE(ctx, (mf_fwd1_a<1>(r, lds, twl, tid)));
+  MF_WPHASE(ctx, (mf_fwd1_b<1>(r, lds, tid)));
+  MF_WPHASE(ctx, (mf_fwd2_a<1>(r, lds, tid)));
+  MF_WPHASE(ctx, (mf_fwd2_b<1>(r, lds, tid)));
+  MVN_PHASE_NOSYNC(ctx, (mf_taps_store(P, lds, batch, c, tid)));
+}

@@ -270,6 +270,11 @@ struct RowsParams {
   // there is no Nyquist plane (in_nyq / out_nyq unused): the dim1 passes then transform DC + i Nyquist as one
   // complex column and the direct dim0 leg separates the two by the k1 <-> -k1 symmetry (mvn_dim0_direct.hpp)
   int nyq_packed;
+  // 1: the half-spectrum (in_cplx / out_cplx) is in the LINE layout of the fused middle pass (mvn_mid_fused.hpp),
+  // [plane][position][row of the plane] with lines_d1 rows per plane; row r of the launch is row row_base + r of the
+  // volume and in_cplx / out_cplx point at the volume's first element.  Fixed kernels only, nyq_packed only.
+  int lines, lines_d1;
+  long row_base;
 };
 
 // forward stages + real<->complex step + store of a tile that already sits in LDS as the packed

@@ -29,7 +29,7 @@ REFERENCE_ABI_SYMBOLS = [
     "getMemDeviceCUDA",
 ]
 ENGINE_ABI_SYMBOLS = [
-    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_get_pad_mode", "mvn_release_cached_engines", "mvn_deconvolve_submit", "mvn_deconvolve_wait", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_multi_device_calls", "mvn_group_create", "mvn_group_destroy", "mvn_group_load", "mvn_group_iterate", "mvn_group_get_psi", "mvn_plan_store_add", "mvn_plan_store_has_key",
+    "mvn_last_error", "mvn_backend_name", "mvn_set_pad_mode", "mvn_get_pad_mode", "mvn_release_cached_engines", "mvn_deconvolve_submit", "mvn_deconvolve_wait", "mvn_psf_cache_counters", "mvn_split_launch_count", "mvn_mid_fused_launch_count", "mvn_multi_device_calls", "mvn_group_create", "mvn_group_destroy", "mvn_group_load", "mvn_group_iterate", "mvn_group_get_psi", "mvn_plan_store_add", "mvn_plan_store_has_key",
     "mvn_plan_store_size", "mvn_plan_store_empty", "mvn_plan_store_clear", "mvn_plan_describe",
     "mvn_fft3_r2c", "mvn_fft3_c2r", "mvn_fft3_time", "mvn_fft3_profile", "mvn_fft3_many_r2c", "mvn_fft3_many_time", "mvn_engine_create", "mvn_engine_destroy",
     "mvn_engine_set_view", "mvn_engine_set_psi", "mvn_engine_get_psi", "mvn_engine_iterate",
@@ -93,6 +93,8 @@ class Binding:
         l.mvn_backend_name.restype = C.c_char_p
         l.mvn_split_launch_count.restype = C.c_long
         l.mvn_split_launch_count.argtypes = []
+        l.mvn_mid_fused_launch_count.restype = C.c_long
+        l.mvn_mid_fused_launch_count.argtypes = []
         l.mvn_multi_device_calls.restype = C.c_long
         l.mvn_multi_device_calls.argtypes = []
         l.mvn_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,

@@ -48,12 +48,10 @@
 #else
 #define MF_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 #endif
-#ifndef MF_SPLIT_ORDER
-#define MF_SPLIT_ORDER 1
-#endif
 #ifndef MF_TW_REGS
 #define MF_TW_REGS 0
 #endif
+
 #if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
 #define MF_WPHASE(ctx, ...)                                         \
   {                                                                 \
@@ -73,8 +71,8 @@
 #define MF_LINES 8        // lines per batch: one per wave
 #define MF_PITCH 576      // cfloats per LDS line: 8 blocks of 64 + 8 spare (the exchanges' bank spreading)
 #define MF_BUF (MF_LINES * MF_PITCH)
-#define MF_TWL 512          // the lanes' twiddles in the LDS: stage 0 [m][l] (m = 1..7, 64 lanes), stage 1 [m][l & 7] behind them
-#define MF_LDS_CFLOATS (2 * MF_BUF + MF_TWL)
+#define MF_TWL 512          // the lanes' twiddles in the LDS (mf_build_twiddles)
+#define MF_LDS_CFLOATS (4 * MF_BUF + MF_TWL)
 
 struct MidFusedParams {
   const cfloat* in;    // [d0][H][MF_N1]
@@ -94,6 +92,7 @@ struct MidFusedParams {
   unsigned poison_epoch;
 };
 enum { MF_CONV = 0, MF_TAPS = 1 };
+enum { MF_DC_NONE = 0, MF_DC_LOW = 1, MF_DC_HIGH = 2, MF_DC_SELF = 3 };  // a work item's bin in the packed DC column
 
 constexpr int mf_slots(int K) { return (K + 7) / 8 * 8; }
 
@@ -107,7 +106,9 @@ struct MfRegs {
   cfloat tw0[8], tw1[8];  // the lane's twiddles (A/B: registers instead of the LDS table)
 #endif
   cfloat bad;
-  int pairwise;   // packed DC column, bins 0 and 256: two REAL streams with two real taps (see below)
+  cfloat t2[8];   // ... of the forward transform that runs beside a transform back
+  cfloat xn, xp;  // the filter's input of the next line (and, DC column, its partner bin), requested a line ahead
+  int dcmode, qm, cpar;  // packed DC column (see below): the bin's kind, its partner bin, the lane's partner offset
 };
 
 inline long mf_pieces(const MidFusedParams& P) { return P.seg > 0 ? (P.d0 + P.seg - 1) / P.seg : 1; }
@@ -158,7 +159,8 @@ MVN_HD void mf_fetch(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int b
 template <int K>
 MVN_HD void mf_setup(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int nsteps, int tid) {
   r.bad = cmake(0.f, 0.f);
-  r.pairwise = 0;
+  r.dcmode = MF_DC_NONE;
+  r.qm = r.cpar = 0;
 #if MF_TW_REGS
 #pragma unroll
   for (int m = 1; m < 8; ++m) {
@@ -173,8 +175,35 @@ MVN_HD void mf_setup(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int n
   mf_fetch<K>(P, r, c, z0, 0, nsteps, tid);
 }
 
+// twiddle products of the transforms here: two packed instructions each (the scalar form of cmul is four; the LDS-
+// staged FFT passes of mvn_fixed.hpp lost time with the packed form, this kernel is short of vector issue slots)
+#ifndef MF_PK_TWIDDLE
+#define MF_PK_TWIDDLE 1
+#endif
+MVN_HD cfloat mf_cmul(cfloat a, cfloat w) {
+#if defined(MVN_PACKED) && MF_PK_TWIDDLE
+  cfloat t, r;
+  MVN_PK2(t, "v_pk_mul_f32", a, w, "op_sel_hi:[0,1]");                                   // (a.x w.x, a.x w.y)
+  MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]");  // + (-a.y w.y, a.y w.x)
+  return r;
+#else
+  return cmul(a, w);
+#endif
+}
+MVN_HD cfloat mf_cmulc(cfloat a, cfloat w) {  // a * conj(w)
+#if defined(MVN_PACKED) && MF_PK_TWIDDLE
+  cfloat t, r;
+  MVN_PK2(t, "v_pk_mul_f32", a, w, "op_sel_hi:[0,1] neg_hi:[0,1]");       // (a.x w.x, -a.x w.y)
+  MVN_PK3(r, "v_pk_fma_f32", a, w, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1]");  // + (a.y w.y, a.y w.x)
+  return r;
+#else
+  return cmulc(a, w);
+#endif
+}
+
 // The lanes' twiddles live in the LDS (they would be 28 registers next to the filter's 126): stage 0, lane l:
-// exp(-2 pi i l m / 512) at [m - 1][l]; stage 1: exp(-2 pi i (l & 7) m / 64) at 448 + [m - 1][l & 7].
+// exp(-2 pi i l m / 512) at [m - 1][l]; stage 1: exp(-2 pi i (l & 7) m / 64) at 448 + [m - 1][l & 7].  (As 16-byte
+// pairs, four reads per stage instead of seven: +4 % on the kernel - tools/mf_ab.sh, profiles/r04_mid_fused.md.)
 MVN_HD void mf_build_twiddles(const MidFusedParams& P, cfloat* twl, int tid) {
   if (tid < 448) {
     const int m = tid / 64 + 1, l = tid & 63;
@@ -184,6 +213,7 @@ MVN_HD void mf_build_twiddles(const MidFusedParams& P, cfloat* twl, int tid) {
     twl[tid] = P.tw[8 * j * m];
   }
 }
+// (fetched one by one where a stage multiplies: all seven up front cost 4 - 20 % of the kernel, as 16-byte pairs 4 %)
 #if MF_TW_REGS
 #define mf_tw0(twl, l, m) (r.tw0[m])
 #define mf_tw1(twl, l, m) (r.tw1[m])
@@ -202,7 +232,7 @@ MVN_HD void mf_fwd0(MfRegs<K>& r, cfloat* buf, const cfloat* twl, int tid) {
   for (int m = 0; m < 8; ++m) a[m] = r.xr[m];
   dftR<8, -1>(a);
 #pragma unroll
-  for (int m = 1; m < 8; ++m) a[m] = cmul(a[m], mf_tw0(twl, l, m));
+  for (int m = 1; m < 8; ++m) a[m] = mf_cmul(a[m], mf_tw0(twl, l, m));
 #pragma unroll
   for (int m = 0; m < 8; ++m) line[72 * m + l] = a[m];  // sub-line m (frequencies m + 8 .), element l
 }
@@ -211,14 +241,62 @@ MVN_HD void mf_fwd0(MfRegs<K>& r, cfloat* buf, const cfloat* twl, int tid) {
 // execute in order: every lane has read before any lane writes); the test-only host emulation, which runs a phase
 // lane after lane, puts a phase boundary between them.
 template <int K>
-MVN_HD void mf_fwd1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
+MVN_HD void mf_fwd1_r(MfRegs<K>& r, const cfloat* buf, int tid) {
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);  // sub-line l >> 3, elements (l & 7) + 8 a
 #pragma unroll
   for (int m = 0; m < 8; ++m) r.t[m] = p[8 * m];
+}
+template <int K>
+MVN_HD void mf_fwd1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
+  const int l = tid & 63;
+  (void)l;
   dftR<8, -1>(r.t);
 #pragma unroll
-  for (int m = 1; m < 8; ++m) r.t[m] = cmul(r.t[m], mf_tw1(twl, l, m));
+  for (int m = 1; m < 8; ++m) r.t[m] = mf_cmul(r.t[m], mf_tw1(twl, l, m));
+}
+// (the same stages on the second register set: in the loop the forward transform of a wave's line runs beside
+// the transform back of its other line)
+template <int K>
+MVN_HD void mf_fwd1_r2(MfRegs<K>& r, const cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.t2[m] = p[8 * m];
+}
+template <int K>
+MVN_HD void mf_fwd1_c2(MfRegs<K>& r, const cfloat* twl, int tid) {
+  const int l = tid & 63;
+  (void)l;
+  dftR<8, -1>(r.t2);
+#pragma unroll
+  for (int m = 1; m < 8; ++m) r.t2[m] = mf_cmul(r.t2[m], mf_tw1(twl, l, m));
+}
+template <int K>
+MVN_HD void mf_fwd1_b2(const MfRegs<K>& r, cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) p[9 * m] = r.t2[m];
+}
+template <int K>
+MVN_HD void mf_fwd2_r2(MfRegs<K>& r, const cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + 9 * (l & 7);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) r.t2[m] = p[m];
+}
+template <int K>
+MVN_HD void mf_fwd2_b2(const MfRegs<K>& r, cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  cfloat* line = buf + wv * MF_PITCH;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) line[64 * m + l] = r.t2[m];
+}
+template <int K>
+MVN_HD void mf_fwd1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
+  mf_fwd1_r<K>(r, buf, tid);
+  mf_fwd1_c<K>(r, twl, tid);
 }
 template <int K>
 MVN_HD void mf_fwd1_b(const MfRegs<K>& r, cfloat* buf, int tid) {
@@ -228,11 +306,15 @@ MVN_HD void mf_fwd1_b(const MfRegs<K>& r, cfloat* buf, int tid) {
   for (int m = 0; m < 8; ++m) p[9 * m] = r.t[m];  // [a' = m][j = l & 7] with pitch 9: both sides conflict-free
 }
 template <int K>
-MVN_HD void mf_fwd2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
+MVN_HD void mf_fwd2_r(MfRegs<K>& r, const cfloat* buf, int tid) {
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + 9 * (l & 7);  // lane (k, a) = (l >> 3, l & 7): its 8 values j
 #pragma unroll
   for (int m = 0; m < 8; ++m) r.t[m] = p[m];
+}
+template <int K>
+MVN_HD void mf_fwd2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
+  mf_fwd2_r<K>(r, buf, tid);
   dftR<8, -1>(r.t);
 }
 template <int K>
@@ -245,11 +327,15 @@ MVN_HD void mf_fwd2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
 
 // ---- inverse transform of a wave's line: LDS line (bins in order q) -> registers in natural order ----
 template <int K>
-MVN_HD void mf_inv2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
+MVN_HD void mf_inv2_r(MfRegs<K>& r, const cfloat* buf, int tid) {
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* line = buf + wv * MF_PITCH;
 #pragma unroll
   for (int m = 0; m < 8; ++m) r.t[m] = line[64 * m + l];
+}
+template <int K>
+MVN_HD void mf_inv2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
+  mf_inv2_r<K>(r, buf, tid);
   dftR<8, +1>(r.t);
 }
 template <int K>
@@ -260,14 +346,24 @@ MVN_HD void mf_inv2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
   for (int m = 0; m < 8; ++m) p[m] = r.t[m];
 }
 template <int K>
-MVN_HD void mf_inv1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
+MVN_HD void mf_inv1_r(MfRegs<K>& r, const cfloat* buf, int tid) {
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
 #pragma unroll
   for (int m = 0; m < 8; ++m) r.t[m] = p[9 * m];
+}
+template <int K>
+MVN_HD void mf_inv1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
+  const int l = tid & 63;
+  (void)l;
 #pragma unroll
-  for (int m = 1; m < 8; ++m) r.t[m] = cmulc(r.t[m], mf_tw1(twl, l, m));
+  for (int m = 1; m < 8; ++m) r.t[m] = mf_cmulc(r.t[m], mf_tw1(twl, l, m));
   dftR<8, +1>(r.t);
+}
+template <int K>
+MVN_HD void mf_inv1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
+  mf_inv1_r<K>(r, buf, tid);
+  mf_inv1_c<K>(r, twl, tid);
 }
 template <int K>
 MVN_HD void mf_inv1_b(const MfRegs<K>& r, cfloat* buf, int tid) {
@@ -277,17 +373,25 @@ MVN_HD void mf_inv1_b(const MfRegs<K>& r, cfloat* buf, int tid) {
   for (int m = 0; m < 8; ++m) p[8 * m] = r.t[m];
 }
 template <int K>
-MVN_HD void mf_inv0_store(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, cfloat* dst, int tid) {
+MVN_HD void mf_inv0_r(MfRegs<K>& r, const cfloat* buf, int tid) {
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* line = buf + wv * MF_PITCH;
-  cfloat a[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) a[m] = line[72 * m + l];
+  for (int m = 0; m < 8; ++m) r.t[m] = line[72 * m + l];
+}
+template <int K>
+MVN_HD void mf_inv0_c_store(MfRegs<K>& r, const cfloat* twl, cfloat* dst, int tid) {
+  const int l = tid & 63;
 #pragma unroll
-  for (int m = 1; m < 8; ++m) a[m] = cmulc(a[m], mf_tw0(twl, l, m));
-  dftR<8, +1>(a);
+  for (int m = 1; m < 8; ++m) r.t[m] = mf_cmulc(r.t[m], mf_tw0(twl, l, m));
+  dftR<8, +1>(r.t);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) dst[l + 64 * m] = a[m];
+  for (int m = 0; m < 8; ++m) dst[l + 64 * m] = r.t[m];
+}
+template <int K>
+MVN_HD void mf_inv0_store(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, cfloat* dst, int tid) {
+  mf_inv0_r<K>(r, buf, tid);
+  mf_inv0_c_store<K>(r, twl, dst, tid);
 }
 
 // line w of batch `batch` is output m = 8 batch + w - (K - 1) of the walk (the first K - 1 steps only fill the window)
@@ -300,64 +404,28 @@ MVN_HD void mf_store_line(const MidFusedParams& P, MfRegs<K>& r, const cfloat* b
   z = z >= P.d0 ? z - P.d0 : z;
   mf_inv0_store<K>(r, buf, twl, P.out + ((long)z * P.H + c) * MF_N1, tid);
 }
-
-// ---- the filter step on the 8 lines of a batch, in place: work item q <-> bin q of every line ----
-// U = (batch mod KW / 8): step n = 8 batch + c fills slot 8 U + c; tap j multiplies the input of step n - j.
-// FILL: the first K - 1 steps of a walk only fill the window.
-template <int K, int U, bool FILL>
-MVN_HD void mf_filter(MfRegs<K>& r, cfloat* buf, int tid) {
-  constexpr int KW = mf_slots(K);
-#pragma unroll
-  for (int c = 0; c < MF_LINES; ++c) {
-    cfloat* p = buf + c * MF_PITCH + tid;
-    const cfloat x = *p;
-    constexpr int S0 = 8 * U;
-    r.w[S0 + c] = x;
-    if (FILL) continue;
-    r.bad = mvn_dim0_track(r.bad, x);
-    cfloat s1, s2;
-    mvn_cmul2(s1, s2, r.w[(S0 + c + KW) % KW], r.tap[0]);
-    if constexpr (K > 1) {
-      cfloat t1, t2;
-      mvn_cmul2(t1, t2, r.w[(S0 + c - 1 + KW) % KW], r.tap[1]);
-#pragma unroll
-      for (int j = 2; j + 1 < K; j += 2) {
-        mvn_cmac2(s1, s2, r.w[(S0 + c - j + 2 * KW) % KW], r.tap[j]);
-        mvn_cmac2(t1, t2, r.w[(S0 + c - j - 1 + 2 * KW) % KW], r.tap[j + 1]);
-      }
-      if (K % 2) mvn_cmac2(s1, s2, r.w[(S0 + c - (K - 1) + 2 * KW) % KW], r.tap[K - 1]);
-      s1 = cadd(s1, t1);
-      s2 = cadd(s2, t2);
-    }
-    const cfloat o = cadd_i<+1>(s1, s2);
-    *p = r.pairwise ? cmake(s1.x, s2.y) : o;
-    MVN_SCHED_FENCE();  // one line at a time: the scheduler would otherwise start all eight at once
-  }
+// (the same in two halves, for the interleaved schedule: the reads are always done, the rest only for an output line)
+template <int K>
+MVN_HD void mf_store_line_c(const MidFusedParams& P, MfRegs<K>& r, const cfloat* twl, int c, int z0, int nout, int batch,
+                            int tid) {
+  const int m = batch * MF_LINES + (tid >> 6) - (K - 1);
+  if (m < 0 || m >= nout) return;
+  int z = z0 + m;
+  z = z >= P.d0 ? z - P.d0 : z;
+  mf_inv0_c_store<K>(r, twl, P.out + ((long)z * P.H + c) * MF_N1, tid);
 }
-template <int K, int U>
-MVN_HD void mf_filter_dispatch(MfRegs<K>& r, cfloat* buf, int u, bool fill, int tid) {
-  if (u == U) {
-    if (fill)
-      mf_filter<K, U, true>(r, buf, tid);
-    else
-      mf_filter<K, U, false>(r, buf, tid);
-    return;
-  }
-  if constexpr (U + 1 < mf_slots(K) / 8) mf_filter_dispatch<K, U + 1>(r, buf, u, fill, tid);
-}
-
-// (a FILL batch still tracks nothing: the planes it reads are tracked by the piece that outputs them.  A step that
-// outputs tracks its newest input in[z + h]: over the pieces of a column every plane exactly once.)
 
 // ---------------------------------------------------------------------------------------------------------
 // Packed DC column.  Column 0 of the volume holds P[y] = x0[y] + i xh[y]: the DC and the Nyquist bin of row y,
 // both real (RowsParams::nyq_packed); after the transform along the line P[f] = X0[f] + i XH[f] with X0, XH
 // Hermitian in f.  The two need different taps (T0, TH; the taps' own column 0 holds T0 + i TH the same way).
-// The workgroup of column 0 therefore separates them behind the forward transform,
-//     X0[f] = (P[f] + conj P[-f]) / 2,    XH[f] = -i (P[f] - conj P[-f]) / 2,
-// lets the work item of bin f (0 < f < 256) filter X0[f] with T0[f] and the work item of bin -f filter XH[f] with
-// TH[f], and puts them together again in front of the inverse transform:
+// In the workgroup of column 0 the work item of bin f (0 < f < 256) filters X0[f] with T0[f] and the work item of
+// bin -f filters XH[f] with TH[f]:
+//     X0[f] = (P[f] + conj P[-f]) / 2,    XH[f] = -i (P[f] - conj P[-f]) / 2
+// - each reads its partner's bin of the line next to its own (the filter step is out of place, so nobody has
+// written there yet) -, and the wave that transforms the line back puts them together again as it reads the line:
 //     R[f] = R0[f] + i RH[f],    R[-f] = conj R0[f] + i conj RH[f].
+// One more LDS read per bin on either side; no pass of its own, no store.
 // f = 0 and f = 256 pair with themselves: X0 and XH are real there, as are the taps, so P[f] IS the pair
 // (X0[f], XH[f]) and the packed tap IS (T0[f], TH[f]); the work items of those two bins filter the two halves
 // separately - with the two chains every work item keeps anyway (s1 runs on the real parts, s2 on the imaginary
@@ -369,11 +437,19 @@ MVN_HD int mf_freq_of(int q) { return ((q >> 3) & 7) + 8 * (q & 7) + 64 * (q >> 
 MVN_HD cfloat mf_herm0(cfloat a, cfloat b) { return cmake(0.5f * (a.x + b.x), 0.5f * (a.y - b.y)); }
 MVN_HD cfloat mf_hermh(cfloat a, cfloat b) { return cmake(0.5f * (a.y + b.y), 0.5f * (b.x - a.x)); }
 
+
 template <int K>
 MVN_HD void mf_setup_dc(const MidFusedParams& P, MfRegs<K>& r, int tid) {
-  const int f = mf_freq_of(tid), fm = (MF_N1 - f) & (MF_N1 - 1), qm = mf_bin_of(fm);
-  r.pairwise = f == fm;
-  const cfloat* tp = P.taps + qm;
+  const int f = mf_freq_of(tid), fm = (MF_N1 - f) & (MF_N1 - 1);
+  r.qm = mf_bin_of(fm);
+  r.dcmode = f == fm ? MF_DC_SELF : (f < MF_N1 / 2 ? MF_DC_LOW : MF_DC_HIGH);
+  // the wave that transforms a line back holds bins 64 m + l: frequency (l >> 3) + 8 (l & 7) + 64 m, whose partner
+  // 512 - f sits in bin 64 (7 - m) + cpar (lane 0: 64 (8 - m), its own bin for m = 0)
+  {
+    const int l = tid & 63, g = (l >> 3) + 8 * (l & 7);
+    r.cpar = g == 0 ? 64 : 8 * ((64 - g) & 7) + ((64 - g) >> 3);
+  }
+  const cfloat* tp = P.taps + r.qm;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const cfloat a = r.tap[j], b = j < P.k ? tp[(long)mf_tap_plane(P, j) * P.H * MF_N1] : cmake(0.f, 0.f);
@@ -382,60 +458,75 @@ MVN_HD void mf_setup_dc(const MidFusedParams& P, MfRegs<K>& r, int tid) {
   }
 }
 
-// behind the forward transform of the wave's line: lane l separates the pairs f = l + 64 m (in place: a pair is
-// touched by one lane only)
-MVN_HD void mf_dc_unpack(cfloat* buf, int tid) {
-  const int wv = tid >> 6, l = tid & 63;
-  cfloat* line = buf + wv * MF_PITCH;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int f = l + 64 * m;
-    if (f == 0) continue;
-    const int q1 = mf_bin_of(f), q2 = mf_bin_of(MF_N1 - f);
-    const cfloat a = line[q1], b = line[q2];
-    line[q1] = mf_herm0(a, b);
-    line[q2] = mf_hermh(a, b);
-  }
+// ---- the filter step, line by line: work item q <-> bin q of every line, `in` -> `out` ----
+// U = (batch mod KW / 8): step n = 8 batch + C fills slot 8 U + C; tap j multiplies the input of step n - j.
+// FILL: the first K - 1 steps of a walk only fill the window.  The input of a line is requested one line ahead
+// (r.xn, in the DC column r.xp as well).
+template <int K>
+MVN_HD void mf_fread(MfRegs<K>& r, const cfloat* in, int c, bool dc, int tid) {
+  r.xn = in[c * MF_PITCH + tid];
+  if (dc) r.xp = in[c * MF_PITCH + r.qm];
 }
-MVN_HD void mf_dc_repack(cfloat* buf, int tid) {
-  const int wv = tid >> 6, l = tid & 63;
-  cfloat* line = buf + wv * MF_PITCH;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int f = l + 64 * m;
-    if (f == 0) continue;
-    const int q1 = mf_bin_of(f), q2 = mf_bin_of(MF_N1 - f);
-    const cfloat a = line[q1], b = line[q2];  // R0[f], RH[f]
-    line[q1] = cmake(a.x - b.y, a.y + b.x);   // R0 + i RH
-    line[q2] = cmake(a.x + b.y, b.x - a.y);   // conj R0 + i conj RH
+template <int K, int U, int C, bool FILL>
+MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc, int tid) {
+  constexpr int KW = mf_slots(K), S = 8 * U + C;
+  cfloat x = r.xn;
+  if (dc) {
+    const cfloat lo = mf_herm0(x, r.xp), hi = mf_hermh(r.xp, x);
+    x = r.dcmode == MF_DC_LOW ? lo : (r.dcmode == MF_DC_HIGH ? hi : x);
   }
+  if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
+  r.w[S] = x;
+  if (FILL) return;
+  r.bad = mvn_dim0_track(r.bad, x);
+  cfloat s1, s2;
+  mvn_cmul2(s1, s2, r.w[S], r.tap[0]);
+  if constexpr (K > 1) {
+    cfloat t1, t2;
+    mvn_cmul2(t1, t2, r.w[(S - 1 + KW) % KW], r.tap[1]);
+#pragma unroll
+    for (int j = 2; j + 1 < K; j += 2) {
+      mvn_cmac2(s1, s2, r.w[(S - j + 2 * KW) % KW], r.tap[j]);
+      mvn_cmac2(t1, t2, r.w[(S - j - 1 + 2 * KW) % KW], r.tap[j + 1]);
+    }
+    if (K % 2) mvn_cmac2(s1, s2, r.w[(S - (K - 1) + 2 * KW) % KW], r.tap[K - 1]);
+    s1 = cadd(s1, t1);
+    s2 = cadd(s2, t2);
+  }
+  cfloat o = cadd_i<+1>(s1, s2);
+  if (dc) o = r.dcmode == MF_DC_SELF ? cmake(s1.x, s2.y) : o;
+  out[C * MF_PITCH + tid] = o;
 }
+template <int K, int C, int U>
+MVN_HD void mf_fline_dispatch(MfRegs<K>& r, const cfloat* in, cfloat* out, int u, bool fill, bool dc, int tid) {
+  if (u == U) {
+    if (fill)
+      mf_filter_line<K, U, C, true>(r, in, out, dc, tid);
+    else
+      mf_filter_line<K, U, C, false>(r, in, out, dc, tid);
+    return;
+  }
+  if constexpr (U + 1 < mf_slots(K) / 8) mf_fline_dispatch<K, C, U + 1>(r, in, out, u, fill, dc, tid);
+}
+// (a FILL batch tracks nothing: the planes it reads are tracked by the piece that outputs them.  A step that
+// outputs tracks its newest input in[z + h]: over the pieces of a column every plane exactly once.)
 
-// the transforms of an iteration: line w of batch i - 1 back and out, line w of batch i + 1 in
-template <int K, typename Ctx>
-MVN_HD void mf_transforms(const MidFusedParams& P, cfloat* oth, const cfloat* twl, int i, int nb, int c, int z0, int nout,
-                          int nsteps, bool dc, Ctx& ctx) {
-  constexpr int NT_ = MF_NT;
-  (void)NT_;
-  if (i >= 1) {
-    if (dc) {
-      MF_WPHASE(ctx, (mf_dc_repack(oth, tid)));
-    }
-    MF_WPHASE(ctx, (mf_inv2_a<K>(r, oth, tid)));
-    MF_WPHASE(ctx, (mf_inv2_b<K>(r, oth, tid)));
-    MF_WPHASE(ctx, (mf_inv1_a<K>(r, oth, twl, tid)));
-    MF_WPHASE(ctx, (mf_inv1_b<K>(r, oth, tid)));
-    MF_WPHASE(ctx, (mf_store_line<K>(P, r, oth, twl, c, z0, nout, i - 1, tid)));
-  }
-  if (i + 1 < nb) {
-    MF_WPHASE(ctx, (mf_fwd0<K>(r, oth, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
-    MF_WPHASE(ctx, (mf_fwd1_a<K>(r, oth, twl, tid)));
-    MF_WPHASE(ctx, (mf_fwd1_b<K>(r, oth, tid)));
-    MF_WPHASE(ctx, (mf_fwd2_a<K>(r, oth, tid)));
-    MF_WPHASE(ctx, (mf_fwd2_b<K>(r, oth, tid)));
-    if (dc) {
-      MF_WPHASE(ctx, (mf_dc_unpack(oth, tid)));
-    }
+// the first stage of the transform back reads the wave's line of filter outputs; in the DC column it reads the
+// partners of its bins as well and puts the two Hermitian halves together
+template <int K>
+MVN_HD void mf_inv2_r_dc(MfRegs<K>& r, const cfloat* buf, int tid) {
+  const int wv = tid >> 6, l = tid & 63;
+  const cfloat* line = buf + wv * MF_PITCH;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const cfloat o = line[64 * m + l];
+    const cfloat p = line[(64 * (7 - m) + r.cpar) & (MF_N1 - 1)];
+    // m < 4: frequencies below 256 (own = R0, partner = RH); m > 4: above (own = RH, partner = R0); m = 4: above,
+    // but lane 0 (f = 256) - like lane 0 of m = 0 (f = 0) - holds a pair that is complete as it is
+    const cfloat low = cmake(o.x - p.y, o.y + p.x), high = cmake(p.x + o.y, o.x - p.y);
+    cfloat v = m < 4 ? low : high;
+    if (m == 0 || m == 4) v = l == 0 ? o : v;
+    r.t[m] = v;
   }
 }
 
@@ -453,32 +544,110 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
   const int nsteps = nout + K - 1;
   const int nb = (nsteps + MF_LINES - 1) / MF_LINES;
   const bool dc = P.packed && c == 0;
-  cfloat* twl = lds + 2 * MF_BUF;
+  cfloat* twl = lds + 4 * MF_BUF;
   MVN_PHASE_NOSYNC(ctx, (mf_setup<K>(P, r, c, z0, nsteps, tid), mf_build_twiddles(P, twl, tid)));
   if (dc) {
     MVN_PHASE_NOSYNC(ctx, (mf_setup_dc<K>(P, r, tid)));
   }
   MVN_PHASE(ctx, (void)0);
-  // Waves 4 .. 7 run the filter step first and the transforms second, waves 0 .. 3 the other way round (the two
-  // work on different buffers): a SIMD's two waves - w and w + 4 - are then in different kinds of code, one in the
-  // filter's multiply-adds while the other waits for its LDS exchanges.  In step, both wait and then both multiply.
+  // Four line buffers: the forward transforms of batch i + 1 go to FW[(i + 1) & 1], the filter step of batch i reads
+  // FW[i & 1] and writes OU[i & 1], the transforms back of batch i - 1 read OU[(i - 1) & 1].  A wave's forward and
+  // backward transform of an iteration are then independent of each other (two lines, two register sets): their
+  // stages run in pairs, the LDS reads of a pair are requested together.
+  // MF_SCHED 0 (default): the lines of the filter step - pure arithmetic on other buffers - are dealt out between the
+  // transform stages, behind their LDS requests.  A/B forms (tools/mf_ab.sh; profiles/r04_mid_fused.md): 2 = every
+  // wave filters first and transforms second, 1 = the other way round, 3 = waves 0 .. 3 one way and waves 4 .. 7 -
+  // which share their SIMDs - the other way; as written (a two-pass loop around the blocks) those spill.
+#ifndef MF_SCHED
+#define MF_SCHED 0
+#endif
 #if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
-  const int filter_first = MF_SPLIT_ORDER ? mvn_uniform((ctx.tid >> 8) & 1) : 0;
+  const int filter_first = MF_SCHED == 3 ? mvn_uniform((ctx.tid >> 8) & 1) : (MF_SCHED == 2);
 #else
-  const int filter_first = 0;
+  const int filter_first = 1;
 #endif
   for (int i = -1; i <= nb; ++i) {
-    cfloat* cur = lds + (i & 1) * MF_BUF;
-    cfloat* oth = lds + ((i + 1) & 1) * MF_BUF;
+    const cfloat* fin = lds + (i & 1) * MF_BUF;
+    cfloat* fout = lds + (2 + (i & 1)) * MF_BUF;
+    cfloat* fwd = lds + ((i + 1) & 1) * MF_BUF;
+    cfloat* inv = lds + (2 + ((i + 1) & 1)) * MF_BUF;
+    const bool T1 = i >= 1, T2 = i + 1 < nb, F = i >= 0 && i < nb;
+    const bool fill = i * MF_LINES + MF_LINES - 1 < K - 1;
+    const int u = F ? i % (mf_slots(K) / 8) : 0;
+#define MF_FLINE(C)                                                                \
+  if (F) {                                                                         \
+    MF_WPHASE(ctx, (mf_fline_dispatch<K, C, 0>(r, fin, fout, u, fill, dc, tid)));  \
+  }
+#if MF_SCHED == 0
+    if (F) {
+      MF_WPHASE(ctx, (mf_fread<K>(r, fin, 0, dc, tid)));
+    }
+#define MF_FLINE_IL(C) MF_FLINE(C)
+#else
+#define MF_FLINE_IL(C)
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
-      if ((pass == 0) != (filter_first != 0)) {
-        mf_transforms<K>(P, oth, twl, i, nb, c, z0, nout, nsteps, dc, ctx);
-      } else if (i >= 0 && i < nb) {
-        const bool fill = i * MF_LINES + MF_LINES - 1 < K - 1;
-        MF_WPHASE(ctx, (mf_filter_dispatch<K, 0>(r, cur, i % (mf_slots(K) / 8), fill, tid)));
+      if ((pass == 0) == (filter_first != 0)) {
+        if (F) {
+          MF_WPHASE(ctx, (mf_fread<K>(r, fin, 0, dc, tid)));
+        }
+        MF_FLINE(0) MF_FLINE(1) MF_FLINE(2) MF_FLINE(3) MF_FLINE(4) MF_FLINE(5) MF_FLINE(6) MF_FLINE(7)
+        continue;
+      }
+#endif
+    // stage pair A: first stage back (reads the line) | first forward stage (reads the registers loaded ahead)
+    if (T1) {
+      if (dc) {
+        MF_WPHASE(ctx, (mf_inv2_r_dc<K>(r, inv, tid)));
+      } else {
+        MF_WPHASE(ctx, (mf_inv2_r<K>(r, inv, tid)));
       }
     }
+    if (T2) {
+      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
+    }
+    MF_FLINE_IL(0)
+    if (T1) {
+      MF_WPHASE(ctx, (dftR<8, +1>(r.t), mf_inv2_b<K>(r, inv, tid)));
+    }
+    // stage pair B
+    if (T1) {
+      MF_WPHASE(ctx, (mf_inv1_r<K>(r, inv, tid)));
+    }
+    if (T2) {
+      MF_WPHASE(ctx, (mf_fwd1_r2<K>(r, fwd, tid)));
+    }
+    MF_FLINE_IL(1)
+    MF_FLINE_IL(2)
+    if (T1) {
+      MF_WPHASE(ctx, (mf_inv1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid)));
+    }
+    if (T2) {
+      MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
+    }
+    // stage pair C
+    if (T1) {
+      MF_WPHASE(ctx, (mf_inv0_r<K>(r, inv, tid)));
+    }
+    if (T2) {
+      MF_WPHASE(ctx, (mf_fwd2_r2<K>(r, fwd, tid)));
+    }
+    MF_FLINE_IL(3)
+    MF_FLINE_IL(4)
+    if (T1) {
+      MF_WPHASE(ctx, (mf_store_line_c<K>(P, r, twl, c, z0, nout, i - 1, tid)));
+    }
+    if (T2) {
+      MF_WPHASE(ctx, (dftR<8, -1>(r.t2), mf_fwd2_b2<K>(r, fwd, tid)));
+    }
+    MF_FLINE_IL(5)
+    MF_FLINE_IL(6)
+    MF_FLINE_IL(7)
+#if MF_SCHED != 0
+    }
+#endif
+#undef MF_FLINE
+#undef MF_FLINE_IL
     MVN_PHASE(ctx, (void)0);
   }
   MVN_PHASE_NOSYNC(ctx, (mf_report<K>(P, r)));
@@ -514,7 +683,7 @@ MVN_HD void mf_taps_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& 
   (void)NT_;
   const long batch = block / P.H;
   const int c = (int)(block - batch * P.H);
-  cfloat* twl = lds + 2 * MF_BUF;
+  cfloat* twl = lds + 4 * MF_BUF;
   MVN_PHASE(ctx, (mf_taps_load(P, r, batch, c, tid), mf_build_twiddles(P, twl, tid)));
   MF_WPHASE(ctx, (mf_fwd0<1>(r, lds, twl, tid)));
   MF_WPHASE(ctx, (mf_fwd1_a<1>(r, lds, twl, tid)));

@@ -1165,3 +1165,60 @@ def test_slabs_of_a_large_volume_keep_the_split_nyquist_layout(emu, monkeypatch)
     finally:
         monkeypatch.delenv("MVN_DEVICES", raising=False)
         emu.l.mvn_release_cached_engines()
+
+
+# ---- round 4: the fused middle pass on the line layout (csrc/mvn_mid_fused.hpp) ----------------------------------
+def _lines_case(shape, kshape, nviews=2, seed=60):
+    _, views, k1, k2, w, psi0 = realistic_views(shape, nviews, kshape, seed=seed)
+    k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]  # an asymmetric second kernel of the same depth
+    return views, k1, k2, w, psi0
+
+
+@pytest.mark.parametrize("shape,kshape", [((12, 512, 512), (3, 5, 3)), ((40, 512, 512), (31, 5, 3)),
+                                          ((36, 512, 512), (16, 3, 3)), ((20, 512, 512), (1, 3, 3))])
+def test_fused_middle_pass_on_the_line_layout_vs_oracle(emu, monkeypatch, shape, kshape):
+    # 512 x 512 planes, PSFs of at most 31 planes: the sequential sweep runs last-axis pass -> ONE middle pass
+    # (dim1 forward, K-tap direct convolution along dim0, dim1 inverse) -> last-axis pass on a half-spectrum whose
+    # lines along dim1 are contiguous, Nyquist bins packed into the DC column.  Odd / even / single-plane / deepest
+    # instantiated PSF depths, lambda 0 and > 0, against the oracle; MVN_MID_FUSED=0 keeps the three-pass middle.
+    monkeypatch.setenv("MVN_PAD_MODE", "none")
+    emu.l.mvn_release_cached_engines()
+    views, k1, k2, w, psi0 = _lines_case(shape, kshape)
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 2)
+        c0 = emu.l.mvn_mid_fused_launch_count()
+        got = emu.gpu_deconvolve(psi0, h)
+        assert emu.l.mvn_mid_fused_launch_count() - c0 == 2 * 2 * 2  # iterations x views x convolutions
+        ref = orc.cpu_deconvolve(psi0, h, 8)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), (shape, kshape, lam)
+    if kshape[0] == 3:
+        monkeypatch.setenv("MVN_MID_FUSED", "0")
+        emu.l.mvn_release_cached_engines()
+        c0 = emu.l.mvn_mid_fused_launch_count()
+        three = emu.gpu_deconvolve(psi0, h)
+        assert emu.l.mvn_mid_fused_launch_count() == c0
+        assert np.abs(three - got).max() <= 1e-5 * np.abs(got).max()
+        monkeypatch.delenv("MVN_MID_FUSED")
+    emu.l.mvn_release_cached_engines()
+
+
+def test_fused_middle_pass_nonfinite_voxel_and_other_loops(emu, monkeypatch):
+    # a non-finite voxel floods the volume through the fused middle pass as it does through an FFT along dim0
+    # (poison word, mvn_dim0_direct.hpp); the simultaneous step of the same engine keeps the three-pass middle
+    # (nonfinite_cases runs both); a PSF deeper than 31 planes on the same shape falls back as a whole
+    monkeypatch.setenv("MVN_PAD_MODE", "none")
+    emu.l.mvn_release_cached_engines()
+    try:
+        c0 = emu.l.mvn_mid_fused_launch_count()
+        nonfinite_cases(emu, (24, 512, 512), (5, 3, 3), (11, 100, 7), its_list=(2,))
+        assert emu.l.mvn_mid_fused_launch_count() > c0
+        shape = (40, 512, 512)
+        views, k1, k2, w, psi0 = _lines_case(shape, (33, 3, 3), nviews=1)
+        h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
+        c0 = emu.l.mvn_mid_fused_launch_count()
+        got = emu.gpu_deconvolve(psi0, h)
+        assert emu.l.mvn_mid_fused_launch_count() == c0
+        ref = orc.cpu_deconvolve(psi0, h, 8)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    finally:
+        emu.l.mvn_release_cached_engines()

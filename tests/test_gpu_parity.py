@@ -1560,3 +1560,68 @@ def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
         fft = np.load(out)
     mx, rms = rel_err(a, fft)
     assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)
+
+
+# ---- round 4: the fused middle pass on the line layout (csrc/mvn_mid_fused.hpp) ----------------------------------
+@pytest.mark.parametrize("shape,kshape", [((64, 512, 512), (31, 7, 5)), ((48, 512, 512), (16, 3, 3)),
+                                          ((40, 512, 512), (9, 31, 31)), ((33, 512, 512), (2, 3, 3))])
+def test_fused_middle_pass_on_the_line_layout_vs_oracle(gpu, orc, monkeypatch, shape, kshape):
+    # 512 x 512 planes, PSFs of at most 31 planes: the sequential sweep runs last-axis pass -> ONE middle pass (dim1
+    # forward, K-tap direct convolution along dim0, dim1 inverse) -> last-axis pass on a half-spectrum whose lines
+    # along dim1 are contiguous, Nyquist bins packed into the DC column (replaces inc/gpu_convolve.cuh:113-142 for
+    # these shapes).  Through the ABI call (pipelined staging: the form is decided from the kernels' extents before
+    # the last view has arrived) and through a resident engine; MVN_MID_FUSED=0 = the three-pass middle.
+    monkeypatch.setenv("MVN_PAD_MODE", "none")
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=61)
+    k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]
+    got = None
+    for lam in (0.0, 0.006):
+        h = WorkspaceHolder(views, k1, k2, w, lam, 1e-4, 3)
+        c0 = gpu.l.mvn_mid_fused_launch_count()
+        got = gpu.gpu_deconvolve(psi0, h)
+        assert gpu.l.mvn_mid_fused_launch_count() - c0 == 3 * 2 * 2  # iterations x views x convolutions
+        ref = orc.cpu_deconvolve(psi0, h, -1)
+        mx, rms = rel_err(got, ref)
+        assert mx <= 1e-5 and rms <= 1e-6, (shape, kshape, lam, mx, rms)
+    eng = gpu.engine(shape, 2)
+    for v in range(2):
+        eng.set_view(v, views[v], w[v], k1[v], k2[v])
+    eng.set_psi(psi0)
+    c0 = gpu.l.mvn_mid_fused_launch_count()
+    eng.iterate(3, 0.006, 1e-4)
+    res = eng.get_psi()
+    eng.close()
+    assert gpu.l.mvn_mid_fused_launch_count() - c0 == 12
+    assert np.array_equal(res, got)  # same passes, same order: bit for bit
+    monkeypatch.setenv("MVN_MID_FUSED", "0")
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    c0 = gpu.l.mvn_mid_fused_launch_count()
+    three = gpu.gpu_deconvolve(psi0, WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3))
+    assert gpu.l.mvn_mid_fused_launch_count() == c0
+    mx, rms = rel_err(three, got)
+    assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+
+
+def test_fused_middle_pass_nonfinite_voxel_and_fallbacks(gpu, orc, monkeypatch):
+    # one Inf voxel (in psi, in a view) floods the volume through the fused middle pass as it does through an FFT
+    # along dim0 (inc/cpu_convolve.h:256-268 + inc/cpu_kernels.h:40-47,76-83); the simultaneous step of the same
+    # shape keeps the three-pass middle (nonfinite_cases runs both loops); a PSF deeper than 31 planes falls back
+    from nonfinite_util import nonfinite_cases
+    monkeypatch.setenv("MVN_PAD_MODE", "none")
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    try:
+        c0 = gpu.l.mvn_mid_fused_launch_count()
+        nonfinite_cases(gpu, (48, 512, 512), (15, 3, 3), (20, 100, 7))
+        assert gpu.l.mvn_mid_fused_launch_count() > c0
+        shape = (48, 512, 512)
+        _, views, k1, k2, w, psi0 = realistic_views(shape, 1, (33, 3, 3), seed=62)
+        h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 1)
+        c0 = gpu.l.mvn_mid_fused_launch_count()
+        got = gpu.gpu_deconvolve(psi0, h)
+        assert gpu.l.mvn_mid_fused_launch_count() == c0
+        mx, rms = rel_err(got, orc.cpu_deconvolve(psi0, h, -1))
+        assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)
+    finally:
+        gpu.check(gpu.l.mvn_release_cached_engines())

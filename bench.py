@@ -251,8 +251,18 @@ def exact_halo_mode(lib, devices, shape, psf_edge, n_views, steps, warmup, check
            "devices": list(devices), "value": round(steps / (ms * 1e-3), 4), "unit": "iterations/s",
            "ms_per_step": round(ms / steps, 4), "steps": steps, "warmup": warmup,
            "psi_finite_positive": bool(np.isfinite(got).all() and (got > 0).all())}
-    # (the slabs run the Nyquist layout the whole volume has on one device: the same arithmetic, bit for bit)
-    e = lib.engine(shape, n_views, device=check_device)
+    # (the slabs run the Nyquist layout the whole volume has on one device and its THREE middle passes - they
+    # exchange halo planes between them -: the same arithmetic as the one-device engine with MVN_MID_FUSED=0, bit for
+    # bit; the fused middle pass a 512^3 engine takes by default differs from it by rounding, see `parity` of the line)
+    saved = os.environ.get("MVN_MID_FUSED")
+    os.environ["MVN_MID_FUSED"] = "0"  # (read when an engine is made)
+    try:
+        e = lib.engine(shape, n_views, device=check_device)
+    finally:
+        if saved is None:
+            os.environ.pop("MVN_MID_FUSED", None)
+        else:
+            os.environ["MVN_MID_FUSED"] = saved
     try:
         for v in range(n_views):
             e.set_view(v, views[v], w, k1s[v], k2s[v])
@@ -265,7 +275,7 @@ def exact_halo_mode(lib, devices, shape, psf_edge, n_views, steps, warmup, check
         one = e.get_psi()
     finally:
         e.close()
-    out["parity"] = {"case": "psi after %d sweeps vs the one-device engine's sequential sweep" % (warmup + steps),
+    out["parity"] = {"case": "psi after %d sweeps vs the one-device engine's sequential sweep (three-pass middle)" % (warmup + steps),
                      "bit_equal": bool(np.array_equal(got, one)),
                      "max_rel": float(np.abs(got.astype(np.float64) - one).max() / np.abs(one).max())}
     return out
@@ -488,6 +498,17 @@ def run_rank(args, world_env):
                         "per_kernel": {k: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1],
                                            "GBps": round(KB(k)[0] / (v[0] / v[1] * 1e-3) / 1e9, 1)}
                                        for k, v in prof.items()}}
+            if kind == "mid_fused":
+                # the fused middle pass is priced against HBM like every pass (the contract's bound), but it is NOT
+                # memory-bound: it does the arithmetic of three passes on one read and one write of the volume
+                K = min(psf_edge, d0)
+                flops = d0 * (d2 // 2) * (d1 * 8.0 * K + 2 * 5.0 * d1 * np.log2(d1))
+                roofline["note"] = ("three passes' arithmetic on one read + one write of the half-spectrum: bound by "
+                                    "vector instruction issue and LDS latency at two waves per SIMD (the filter's 126 "
+                                    "registers per bin), not by HBM - DESIGN.md section 4, profiles/r04_mid_fused.md")
+                roofline["vector_f32"] = {"flop_per_launch": flops, "achieved_TFLOPs": round(flops / (avg_ms * 1e-3) / 1e12, 1),
+                                          "peak_TFLOPs_packed_f32": 157.3,
+                                          "frac": round(flops / (avg_ms * 1e-3) / 1e12 / 157.3, 4)}
             traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(traffic_file) and shape == (512, 512, 512):  # PMC passes were taken at 512^3
                 try:

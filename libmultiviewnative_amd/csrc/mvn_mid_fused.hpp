@@ -561,6 +561,9 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
 #ifndef MF_SCHED
 #define MF_SCHED 0
 #endif
+#ifndef MF_PRIO_T
+#define MF_PRIO_T 2  // (A/B, with -DMF_PRIO: issue priority of a wave outside the filter step's lines)
+#endif
 #if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
   const int filter_first = MF_SCHED == 3 ? mvn_uniform((ctx.tid >> 8) & 1) : (MF_SCHED == 2);
 #else
@@ -574,9 +577,16 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     const bool T1 = i >= 1, T2 = i + 1 < nb, F = i >= 0 && i < nb;
     const bool fill = i * MF_LINES + MF_LINES - 1 < K - 1;
     const int u = F ? i % (mf_slots(K) / 8) : 0;
+#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && defined(MF_PRIO)
+#define MF_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define MF_SETPRIO(p) (void)0
+#endif
 #define MF_FLINE(C)                                                                \
   if (F) {                                                                         \
+    MF_SETPRIO(0);                                                                 \
     MF_WPHASE(ctx, (mf_fline_dispatch<K, C, 0>(r, fin, fout, u, fill, dc, tid)));  \
+    MF_SETPRIO(MF_PRIO_T);                                                         \
   }
 #if MF_SCHED == 0
     if (F) {

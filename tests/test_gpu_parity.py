@@ -1224,18 +1224,30 @@ def test_slabs_of_a_large_volume_keep_the_split_nyquist_layout(gpu, orc, monkeyp
             ref = orc.cpu_deconvolve(psi0, h, 8)
             mx, rms = rel_err(single, ref)
             assert mx <= MAX_REL and rms <= RMS_REL, (shape, mx, rms)
+            if shape[1:] == (512, 512):
+                # on 512 x 512 planes ONE device runs the fused middle pass (csrc/mvn_mid_fused.hpp); slabs keep the
+                # three passes they exchange halo planes between: their result is the three-pass one-device result
+                # bit for bit, and the fused one to rounding
+                fused = single
+                monkeypatch.setenv("MVN_MID_FUSED", "0")
+                gpu.check(gpu.l.mvn_release_cached_engines())
+                single = gpu.gpu_deconvolve(psi0, h)
+                mx, rms = rel_err(single, fused)
+                assert mx <= 1e-5 and rms <= 1e-6, (shape, mx, rms)
             for devices in ("0,0", "0,0,0"):
                 monkeypatch.setenv("MVN_DEVICES", devices)
                 before = gpu.l.mvn_multi_device_calls()
                 multi = gpu.gpu_deconvolve(psi0, h)
                 assert gpu.l.mvn_multi_device_calls() == before + 1
                 assert np.array_equal(multi, single), (shape, devices)
+            monkeypatch.delenv("MVN_MID_FUSED", raising=False)
             if shape[0] == 48:
                 bad = psi0.copy()
                 bad[5, 5, 5] = np.inf
                 assert np.array_equal(gpu.gpu_deconvolve(bad, h), orc.cpu_deconvolve(bad, h, 4), equal_nan=True)
     finally:
         monkeypatch.delenv("MVN_DEVICES", raising=False)
+        monkeypatch.delenv("MVN_MID_FUSED", raising=False)
         gpu.check(gpu.l.mvn_release_cached_engines())
 
 
@@ -1514,9 +1526,12 @@ def test_default_policy_keeps_dim0_exact_under_the_direct_leg(gpu, orc, monkeypa
 
 
 def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
-    # (64, 512, 512) x 2 views x 31-plane PSFs: big enough planes for the direct dim0 leg by default.  Two runs
-    # from the same psi are bit-identical (no atomics, no order dependence on the staggered walk), and the
-    # direct leg agrees with the fused FFT leg of the same library to rounding.
+    # (64, 512, 512) x 2 views x 31-plane PSFs: the shape class of the headline - planes of 512 x 512, where the
+    # three middle passes run as ONE (csrc/mvn_mid_fused.hpp; round 3 / first half of round 4: the direct dim0 leg
+    # between two dim1 passes).  Two runs from the same psi are bit-identical (no atomics, no order dependence), and
+    # the result agrees to rounding with the three-pass middle (MVN_MID_FUSED=0: direct leg) and with the fused FFT
+    # leg (MVN_DIM0_DIRECT=0) of the same library, each in a child process (the switches are read per engine, the
+    # kernels' A/B knobs once per process).
     import subprocess
     import sys
     shape, V = (64, 512, 512), 2
@@ -1539,7 +1554,7 @@ def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
 
     a, kinds = run()
     b, _ = run()
-    assert "axis0_direct" in kinds and "axis0_fused" not in kinds, kinds
+    assert "mid_fused" in kinds and not {"axis0_direct", "axis0_fused", "axis1_fwd", "axis1_inv"} & kinds, kinds
     assert np.array_equal(a, b)
     code = ("import os, sys, numpy as np\n"
             "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
@@ -1553,13 +1568,13 @@ def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "fft.npy")
-        r = subprocess.run([sys.executable, "-c", code % (root, root), out], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, MVN_DIM0_DIRECT="0"))
-        assert r.returncode == 0, r.stderr[-3000:]
-        fft = np.load(out)
-    mx, rms = rel_err(a, fft)
-    assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)
+        for tag, env in (("fft", {"MVN_DIM0_DIRECT": "0"}), ("three", {"MVN_MID_FUSED": "0"})):
+            out = os.path.join(d, tag + ".npy")
+            r = subprocess.run([sys.executable, "-c", code % (root, root), out], capture_output=True, text=True,
+                               timeout=600, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-3000:]
+            mx, rms = rel_err(a, np.load(out))
+            assert mx <= 1e-5 and rms <= 1e-6, (tag, mx, rms)
 
 
 # ---- round 4: the fused middle pass on the line layout (csrc/mvn_mid_fused.hpp) ----------------------------------

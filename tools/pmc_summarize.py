@@ -23,6 +23,11 @@ KINDS = {
     "kx_strided<512, 1>": ["axis1_inv"],
     "kx_strided<512, 2>": ["axis0_fused"],
     "kd_dim0<31, 4>": ["axis0_direct"],  # tools/pmc_probe.py uses 31^3 kernels
+    "kf_mid<31>": ["mid_fused"],  # the three middle passes as one (csrc/mvn_mid_fused.hpp)
+    "kx_rows_c2r_r2c<256, 1, true>": ["rows_fused_div"],  # line-layout forms of the tiled last-axis kernels
+    "kx_rows_c2r_r2c<256, 2, true>": ["rows_fused_upd"],
+    "kx_rows_r2c<256, true>": ["rows_r2c"],
+    "kx_rows_c2r<256, 2, true>": ["rows_c2r"],
     "kx_rows_c2r_r2c<256, 1>": ["rows_fused_div"],
     "kw_rows<2, 1>": ["rows_fused_div"],
     "kw_rows<2, 2>": ["rows_fused_upd"],
@@ -57,7 +62,7 @@ def main():
     vol = 4 * 512 ** 3
     B = vol + 8 * 512 * 512
     algorithmic = {"rows_r2c": vol + B, "axis1_fwd": 2 * vol, "axis1_inv": 2 * vol, "axis0_fused": 3 * vol,
-                   "axis0_direct": (2 + 31.0 / 512) * B,
+                   "axis0_direct": (2 + 31.0 / 512) * B, "mid_fused": (2 + 31.0 / 512) * vol,
                    "rows_fused_div": 2 * B + vol, "rows_fused_upd": 2 * B + 3 * vol, "rows_c2r": B + 3 * vol}
     traffic, lines = {}, []
     for name in sorted(set(rd) | set(wr)):

@@ -1703,7 +1703,9 @@ void Engine::compute_delta_head(double lambda, float min_value) {
   {
     const bool was = packed_;
     decide_layout();
-    if (was != packed_) psi_spec_valid_ = false;  // the chunk-fed spectrum of psi is in the other layout
+    decide_lines();
+    // the chunk-fed spectrum of psi is in the other layout
+    if (was != packed_ || (psi_spec_valid_ && psi_spec_lines_ != lines_)) psi_spec_valid_ = false;
   }
   const Plan3D& P = *plan_;
   // event pairs around every launch cost ~3 % of a sweep: sample like iterate() does
@@ -1721,9 +1723,14 @@ void Engine::compute_delta_head(double lambda, float min_value) {
   const bool use_side = !no_side && side_.s && P.L.even && P.main_bytes() > side_min_bytes && !packed_ && !P.nyq_rides();
   be::stream_t sn = use_side ? side_.s : stream_;
   if (!psi_spec_valid_) {  // else: left there chunk by chunk by apply_delta_chunk(.., feed_next)
-    P.rows_r2c(psi_, (cfloat*)psi_spec_, pn(), stream_, prof);
-    if (use_side) side_.fork_from(stream_);
-    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, pn(), stream_, prof, sn);
+    if (lines_) {  // line layout: the fused middle pass transforms along dim1 itself
+      P.rows_r2c(psi_, (cfloat*)psi_spec_, nullptr, stream_, prof, 0, -1, true);
+    } else {
+      P.rows_r2c(psi_, (cfloat*)psi_spec_, pn(), stream_, prof);
+      if (use_side) side_.fork_from(stream_);
+      P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, pn(), stream_, prof, sn);
+    }
+    psi_spec_lines_ = lines_;
   }
   psi_spec_valid_ = false;  // consumed by this step; psi changes when the correction is applied
   for (int v = 0; v < V; ++v) {
@@ -1747,6 +1754,29 @@ void Engine::compute_delta_head(double lambda, float min_value) {
     e2.lambda = lambda;
     e2.lambda_inv = lambda > 0 ? (float)(1.f / lambda) : 0.f;
     e2.min_value = min_value;
+    if (lines_) {
+      // line layout: psi's last-axis spectrum -> ONE middle pass -> fused divide -> ONE middle pass -> correction
+      if (!s.taps_l_ok[0] || !s.tap_k[0]) throw std::logic_error("mvn: fused middle pass with a kernel that is not in its form");
+      if (++epoch_ == 0x7fffffffu) {
+        be::dzero(poison_, sizeof(unsigned), stream_);
+        epoch_ = 1;
+      }
+      armed_epoch_ = epoch_;
+      P.mid_fused((const cfloat*)psi_spec_, (cfloat*)work_, (const cfloat*)s.taps_l[0], s.tap_k[0], s.tap_kd[0], poison_,
+                  epoch_, stream_, prof);
+      arm(e1);
+      P.rows_c2r_r2c((cfloat*)work_, nullptr, e1, stream_, prof, 0, -1, true);
+      mid_fused_conv(s, 1, prof);
+      arm(e2);
+      if (v + 1 < V) {
+        P.rows_c2r((const cfloat*)work_, nullptr, psi_, e2, stream_, prof, 0, -1, true);
+      } else {
+        tail_epi_ = e2;
+        tail_prof_ = prof;
+        tail_pending_ = true;
+      }
+      continue;
+    }
     // convolution 1 from the shared spectrum of psi; the Nyquist-plane launches ride on the side
     // stream (forked per view: the previous view's last pass still reads work_nyq_, and the
     // chunk-fed spectrum of psi was written on the main stream)
@@ -1793,8 +1823,8 @@ void Engine::compute_delta_chunk(int c, int n) {
     return;
   }
   if (!tail_pending_) throw std::logic_error("mvn: compute_delta_chunk without compute_delta_head");
-  plan_->rows_c2r((const cfloat*)work_, wn(), psi_, tail_epi_, stream_, c == 0 ? tail_prof_ : nullptr,
-                  (long)z0 * L.d1, (long)nz * L.d1);
+  plan_->rows_c2r((const cfloat*)work_, lines_ ? nullptr : wn(), psi_, tail_epi_, stream_, c == 0 ? tail_prof_ : nullptr,
+                  (long)z0 * L.d1, (long)nz * L.d1, lines_);
   if (c == n - 1) tail_pending_ = false;
 }
 
@@ -1817,9 +1847,14 @@ void Engine::apply_delta_chunk(int c, int n, bool feed_next) {
       psi_spec_ = (float*)be::dmalloc(P.main_bytes());
       if (P.nyq_bytes()) psi_spec_nyq_ = (cfloat*)be::dmalloc(P.nyq_bytes());
     }
-    P.rows_r2c(psi_, (cfloat*)psi_spec_, pn(), stream_, nullptr, (long)z0 * P.L.d1,
-               (long)nz * P.L.d1);
-    P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, pn(), stream_, nullptr, stream_, z0, nz);
+    if (lines_) {  // (the layout of the step this correction belongs to; the next head checks it against its own)
+      P.rows_r2c(psi_, (cfloat*)psi_spec_, nullptr, stream_, nullptr, (long)z0 * P.L.d1, (long)nz * P.L.d1, true);
+    } else {
+      P.rows_r2c(psi_, (cfloat*)psi_spec_, pn(), stream_, nullptr, (long)z0 * P.L.d1,
+                 (long)nz * P.L.d1);
+      P.axis1(MVN_ST_FWD, (cfloat*)psi_spec_, pn(), stream_, nullptr, stream_, z0, nz);
+    }
+    psi_spec_lines_ = lines_;
     if (++fed_ == n) {  // every plane of the spectrum belongs to the new psi
       psi_spec_valid_ = true;
       fed_ = 0;

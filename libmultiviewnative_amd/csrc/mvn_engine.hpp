@@ -415,9 +415,10 @@ class Engine {
   cfloat* wn() const { return packed_ ? nullptr : work_nyq_; }
   cfloat* pn() const { return packed_ ? nullptr : psi_spec_nyq_; }
   bool packed_ = false, packed_hint_ = false, packed_allowed_ = true;
-  // the sequential sweep runs its convolutions as last-axis pass -> fused middle pass -> last-axis pass on the
-  // line layout (decided per iterate() call; every other loop form keeps the three-pass middle)
+  // the loops run their convolutions as last-axis pass -> fused middle pass -> last-axis pass on the line layout
+  // (decided per iterate() call / per simultaneous step; halo and slab modes keep the three-pass middle)
   bool lines_capable_ = false, lines_ = false, lines_hint_ = false, lines_last_sweep_ = false;
+  bool psi_spec_lines_ = false;  // the shared spectrum of psi (simultaneous steps) is in the line layout
   void decide_lines();
   void mid_fused_conv(const ViewSlot& s, int i, Profiler* prof);
   halo_fn_t halo_fn_ = nullptr;

@@ -1222,3 +1222,41 @@ def test_fused_middle_pass_nonfinite_voxel_and_other_loops(emu, monkeypatch):
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     finally:
         emu.l.mvn_release_cached_engines()
+
+
+def test_fused_middle_pass_in_the_simultaneous_loop(emu):
+    # the simultaneous (Jacobi) step of the sharded driver on 512 x 512 planes: psi's last-axis spectrum once per
+    # step (line layout), per view ONE middle pass -> fused divide -> ONE middle pass -> correction; whole steps,
+    # the chunked form with the next step's spectrum fed chunk by chunk (Engine::apply_delta_chunk), and a
+    # sequential sweep on the same engine afterwards
+    shape = (24, 512, 512)
+    views, k1, k2, w, psi0 = _lines_case(shape, (5, 3, 3))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, 8)
+    e = emu.engine(shape, 2)
+    try:
+        for v in range(2):
+            e.set_view(v, views[v], w[v], k1[v], k2[v])
+        e.set_psi(psi0)
+        c0 = emu.l.mvn_mid_fused_launch_count()
+        for _ in range(2):
+            e.compute_delta(0.006, 1e-4)
+            e.apply_delta()
+        assert emu.l.mvn_mid_fused_launch_count() - c0 == 2 * 2 * 2
+        whole = e.get_psi()
+        assert np.abs(whole - ref).max() <= 1e-5 * np.abs(ref).max()
+        e.set_psi(psi0)
+        n = e.delta_chunks(4)
+        for _ in range(2):
+            e.compute_delta_head(0.006, 1e-4)
+            for c in range(n):
+                e.compute_delta_chunk(c, n)
+            for c in range(n):
+                e.apply_delta_chunk(c, n, True)
+        assert np.array_equal(e.get_psi(), whole)
+        e.set_psi(psi0)
+        e.iterate(2, 0.006, 1e-4)
+        seq = orc.cpu_deconvolve(psi0, h, 8)
+        assert np.abs(e.get_psi() - seq).max() <= 1e-5 * np.abs(seq).max()
+    finally:
+        e.close()

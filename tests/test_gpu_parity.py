@@ -1640,3 +1640,38 @@ def test_fused_middle_pass_nonfinite_voxel_and_fallbacks(gpu, orc, monkeypatch):
         assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)
     finally:
         gpu.check(gpu.l.mvn_release_cached_engines())
+
+
+def test_fused_middle_pass_in_the_simultaneous_loop(gpu, orc):
+    # the simultaneous (Jacobi) step - what every rank of the view-sharded run computes - on 512 x 512 planes: psi's
+    # last-axis spectrum once per step in the line layout, per view ONE middle pass -> fused divide -> ONE middle pass
+    # -> correction; whole steps and the chunked form (next step's spectrum fed chunk by chunk) against the oracle's
+    # simultaneous loop (test_config3_eight_views_simultaneous_512_vs_oracle runs the same path at full size)
+    shape, V = (48, 512, 512), 3
+    _, views, k1, k2, w, psi0 = realistic_views(shape, V, (15, 5, 3), seed=63)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    ref = orc.cpu_deconvolve_simultaneous(psi0, h, -1)
+    e = gpu.engine(shape, V)
+    try:
+        for v in range(V):
+            e.set_view(v, views[v], w[v], k1[v], k2[v])
+        e.set_psi(psi0)
+        c0 = gpu.l.mvn_mid_fused_launch_count()
+        for _ in range(2):
+            e.compute_delta(0.006, 1e-4)
+            e.apply_delta()
+        assert gpu.l.mvn_mid_fused_launch_count() - c0 == 2 * V * 2
+        whole = e.get_psi()
+        mx, rms = rel_err(whole, ref)
+        assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)
+        e.set_psi(psi0)
+        n = e.delta_chunks(4)
+        for _ in range(2):
+            e.compute_delta_head(0.006, 1e-4)
+            for c in range(n):
+                e.compute_delta_chunk(c, n)
+            for c in range(n):
+                e.apply_delta_chunk(c, n, True)
+        assert np.array_equal(e.get_psi(), whole)
+    finally:
+        e.close()

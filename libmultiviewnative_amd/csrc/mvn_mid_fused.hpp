@@ -467,32 +467,55 @@ MVN_HD void mf_fread(MfRegs<K>& r, const cfloat* in, int c, bool dc, int tid) {
   r.xn = in[c * MF_PITCH + tid];
   if (dc) r.xp = in[c * MF_PITCH + r.qm];
 }
-template <int K, int U, int C, bool FILL>
-MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc, int tid) {
-  constexpr int KW = mf_slots(K), S = 8 * U + C;
+template <int K>
+MVN_HD cfloat mf_filter_input(MfRegs<K>& r, bool dc) {
   cfloat x = r.xn;
   if (dc) {
     const cfloat lo = mf_herm0(x, r.xp), hi = mf_hermh(r.xp, x);
     x = r.dcmode == MF_DC_LOW ? lo : (r.dcmode == MF_DC_HIGH ? hi : x);
   }
-  if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
-  r.w[S] = x;
-  if (FILL) return;
-  r.bad = mvn_dim0_track(r.bad, x);
-  cfloat s1, s2;
-  mvn_cmul2(s1, s2, r.w[S], r.tap[0]);
-  if constexpr (K > 1) {
-    cfloat t1, t2;
-    mvn_cmul2(t1, t2, r.w[(S - 1 + KW) % KW], r.tap[1]);
-#pragma unroll
-    for (int j = 2; j + 1 < K; j += 2) {
-      mvn_cmac2(s1, s2, r.w[(S - j + 2 * KW) % KW], r.tap[j]);
-      mvn_cmac2(t1, t2, r.w[(S - j - 1 + 2 * KW) % KW], r.tap[j + 1]);
-    }
-    if (K % 2) mvn_cmac2(s1, s2, r.w[(S - (K - 1) + 2 * KW) % KW], r.tap[K - 1]);
-    s1 = cadd(s1, t1);
-    s2 = cadd(s2, t2);
+  return x;
+}
+template <int K, int U, int C, bool FILL>
+MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc, int tid) {
+  constexpr int KW = mf_slots(K), S = 8 * U + C;
+  if (FILL) {
+    r.w[S] = mf_filter_input<K>(r, dc);
+    if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
+    return;
   }
+  // OLDEST taps first: they multiply values that have sat in the registers for up to K steps.  The line's own input
+  // x - requested one line ahead, and behind it the reads of the transform stage this line is dealt out behind - is
+  // not touched before the last multiply-adds: taken first, the wave waited for all those reads at the line's first
+  // instruction.  (Slot S, which x replaces, is read by no tap j >= 1.)
+  // FOUR chains (taps j mod 4), two accumulators each: an instruction and the next one of its chain are eight apart.
+  // With two chains the compiler put a wait state (`s_nop`, an issue slot of its own: 4 cycles) between every pair of
+  // multiply-adds - it asks for three instructions between an inline instruction and a reader of its result.
+  constexpr int NC = K < 4 ? K : 4;
+  cfloat a1[NC], a2[NC];
+#pragma unroll
+  for (int j = K - 1; j >= 1; --j) {
+    const int ch = j % NC;
+    const bool first = j + NC > K - 1;  // the largest tap index of its chain
+    if (first)
+      mvn_cmul2(a1[ch], a2[ch], r.w[(S - j + 2 * KW) % KW], r.tap[j]);
+    else
+      mvn_cmac2(a1[ch], a2[ch], r.w[(S - j + 2 * KW) % KW], r.tap[j]);
+  }
+  const cfloat x = mf_filter_input<K>(r, dc);
+  if (K <= NC)  // (chain 0 holds tap 0 alone)
+    mvn_cmul2(a1[0], a2[0], x, r.tap[0]);
+  else
+    mvn_cmac2(a1[0], a2[0], x, r.tap[0]);
+  cfloat s1 = a1[0], s2 = a2[0];
+#pragma unroll
+  for (int ch = 1; ch < NC; ++ch) {
+    s1 = cadd(s1, a1[ch]);
+    s2 = cadd(s2, a2[ch]);
+  }
+  r.w[S] = x;
+  if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
+  r.bad = mvn_dim0_track(r.bad, x);
   cfloat o = cadd_i<+1>(s1, s2);
   if (dc) o = r.dcmode == MF_DC_SELF ? cmake(s1.x, s2.y) : o;
   out[C * MF_PITCH + tid] = o;
@@ -605,7 +628,14 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
         continue;
       }
 #endif
-    // stage pair A: first stage back (reads the line) | first forward stage (reads the registers loaded ahead)
+    // Stages A, B, C: the transform back and the forward transform side by side, their reads requested together.
+    // (MF_FWD_SHIFT=1, A/B: the forward transform one stage behind, in B, C, D - so that it does not wait for its
+    // line, and with it for the global stores of the batch before, right behind the barrier: +8 %, a fourth
+    // stage in the iteration's chain costs more than that wait.)
+#ifndef MF_FWD_SHIFT
+#define MF_FWD_SHIFT 0
+#endif
+    // stage A
     if (T1) {
       if (dc) {
         MF_WPHASE(ctx, (mf_inv2_r_dc<K>(r, inv, tid)));
@@ -613,34 +643,48 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
         MF_WPHASE(ctx, (mf_inv2_r<K>(r, inv, tid)));
       }
     }
+#if !MF_FWD_SHIFT
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
     }
+#endif
     MF_FLINE_IL(0)
     if (T1) {
       MF_WPHASE(ctx, (dftR<8, +1>(r.t), mf_inv2_b<K>(r, inv, tid)));
     }
-    // stage pair B
+    // stage B
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_r<K>(r, inv, tid)));
     }
+#if MF_FWD_SHIFT
+    if (T2) {
+      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
+    }
+#else
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_r2<K>(r, fwd, tid)));
     }
+#endif
     MF_FLINE_IL(1)
     MF_FLINE_IL(2)
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid)));
     }
+#if !MF_FWD_SHIFT
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
     }
-    // stage pair C
+#endif
+    // stage C
     if (T1) {
       MF_WPHASE(ctx, (mf_inv0_r<K>(r, inv, tid)));
     }
     if (T2) {
+#if MF_FWD_SHIFT
+      MF_WPHASE(ctx, (mf_fwd1_r2<K>(r, fwd, tid)));
+#else
       MF_WPHASE(ctx, (mf_fwd2_r2<K>(r, fwd, tid)));
+#endif
     }
     MF_FLINE_IL(3)
     MF_FLINE_IL(4)
@@ -648,10 +692,25 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
       MF_WPHASE(ctx, (mf_store_line_c<K>(P, r, twl, c, z0, nout, i - 1, tid)));
     }
     if (T2) {
+#if MF_FWD_SHIFT
+      MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
+#else
       MF_WPHASE(ctx, (dftR<8, -1>(r.t2), mf_fwd2_b2<K>(r, fwd, tid)));
+#endif
     }
+    // stage D
+#if MF_FWD_SHIFT
+    if (T2) {
+      MF_WPHASE(ctx, (mf_fwd2_r2<K>(r, fwd, tid)));
+    }
+#endif
     MF_FLINE_IL(5)
     MF_FLINE_IL(6)
+#if MF_FWD_SHIFT
+    if (T2) {
+      MF_WPHASE(ctx, (dftR<8, -1>(r.t2), mf_fwd2_b2<K>(r, fwd, tid)));
+    }
+#endif
     MF_FLINE_IL(7)
 #if MF_SCHED != 0
     }

@@ -718,6 +718,7 @@ Engine::Engine(int device, const shape_t& dims, int num_views) : device_(device)
   // the whole iteration is 6.7 / 4.1 % faster than with the fused FFT pass at 15 / 31 planes
   direct_enabled_ = env_int("MVN_DIM0_DIRECT", 1) != 0;
   lines_capable_ = plan_->lines_capable() && env_int("MVN_MID_FUSED", 1) != 0;
+  lines_forced_ = env_int("MVN_MID_FUSED", 1) >= 2;
   direct_max_taps_ = env_int("MVN_DIM0_DIRECT_MAX", MVN_D0_MAX_TAPS);
   direct_min_plane_ = env_int("MVN_DIM0_DIRECT_MIN_PLANE", 131072);  // see direct_ok_for()
   direct_min_items_ = env_int("MVN_DIM0_DIRECT_MIN_ITEMS", 0);
@@ -1102,8 +1103,15 @@ void Engine::decide_layout() {
 
 bool Engine::would_be_direct(const int* kdims) { return direct_form(kdims); }
 
+// A whole column walks d0 + K - 1 steps for d0 outputs (the first K - 1 fill the filter's window).  Measured per view
+// update on (d0, 512, 512) volumes (tools/mid_fused_planes.py, profiles/r04_mid_fused.md): with 31-plane PSFs the two
+// forms meet at 96 - 128 planes (48: +10 %, 256: -15 %, 512: -18 %), with 15 planes the fused pass is ahead from 32
+// planes on (-2 %; 256: -24 %), with 5 planes always (-12 .. -30 %): three PSF depths of planes.
+// MVN_MID_FUSED=2 takes the fused pass whenever the shape has it (tests).
+bool Engine::lines_worth(int k0) const { return lines_forced_ || plan_->L.d0 >= 3 * k0; }
+
 bool Engine::would_be_lines(const int* kdims) {
-  return lines_capable_ && direct_form(kdims) && mvn_dim0_taps_template(kdims[0]) <= 31 &&
+  return lines_capable_ && lines_worth(kdims[0]) && direct_form(kdims) && mvn_dim0_taps_template(kdims[0]) <= 31 &&
          taps_plan(((kdims[0] + 1 + 15) / 16) * 16)->lines_capable();
 }
 
@@ -1118,7 +1126,8 @@ void Engine::decide_lines() {
       all = lines_hint_;
     } else {
       for (size_t v = 0; v < views_.size() && all; ++v)
-        all = views_[v].set && views_[v].tap_k[0] && views_[v].tap_k[1] && views_[v].taps_l_ok[0] && views_[v].taps_l_ok[1];
+        all = views_[v].set && views_[v].tap_k[0] && views_[v].tap_k[1] && views_[v].taps_l_ok[0] && views_[v].taps_l_ok[1] &&
+              lines_worth(views_[v].tap_k[0]) && lines_worth(views_[v].tap_k[1]);
     }
   }
   lines_ = lines_last_sweep_ = all;

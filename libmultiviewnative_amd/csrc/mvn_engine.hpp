@@ -419,6 +419,8 @@ class Engine {
   // (decided per iterate() call / per simultaneous step; halo and slab modes keep the three-pass middle)
   bool lines_capable_ = false, lines_ = false, lines_hint_ = false, lines_last_sweep_ = false;
   bool psi_spec_lines_ = false;  // the shared spectrum of psi (simultaneous steps) is in the line layout
+  bool lines_forced_ = false;    // MVN_MID_FUSED=2: whenever the shape has the pass, however few planes
+  bool lines_worth(int k0) const;
   void decide_lines();
   void mid_fused_conv(const ViewSlot& s, int i, Profiler* prof);
   halo_fn_t halo_fn_ = nullptr;

@@ -104,6 +104,8 @@ struct MfRegs {
   cfloat t[8];    // a transform stage's values between its reads and its writes
 #if MF_TW_REGS
   cfloat tw0[8], tw1[8];  // the lane's twiddles (A/B: registers instead of the LDS table)
+#elif MF_TW1_REGS
+  cfloat tw1[8];
 #endif
   cfloat bad;
   cfloat t2[8];   // ... of the forward transform that runs beside a transform back
@@ -167,6 +169,9 @@ MVN_HD void mf_setup(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int n
     r.tw0[m] = P.tw[(tid & 63) * m];
     r.tw1[m] = P.tw[8 * (tid & 7) * m];
   }
+#elif MF_TW1_REGS
+#pragma unroll
+  for (int m = 1; m < 8; ++m) r.tw1[m] = P.tw[8 * (tid & 7) * m];
 #endif
 #pragma unroll
   for (int j = 0; j < K; ++j) r.tap[j] = j < P.k ? P.taps[((long)mf_tap_plane(P, j) * P.H + c) * MF_N1 + tid] : cmake(0.f, 0.f);
@@ -214,12 +219,19 @@ MVN_HD void mf_build_twiddles(const MidFusedParams& P, cfloat* twl, int tid) {
   }
 }
 // (fetched one by one where a stage multiplies: all seven up front cost 4 - 20 % of the kernel, as 16-byte pairs 4 %)
+#ifndef MF_TW1_REGS
+#define MF_TW1_REGS 0  // A/B: the seven stage-1 twiddles of a lane in registers (14 of them), stage 0's in the LDS
+#endif
 #if MF_TW_REGS
 #define mf_tw0(twl, l, m) (r.tw0[m])
 #define mf_tw1(twl, l, m) (r.tw1[m])
 #else
 MVN_HD cfloat mf_tw0(const cfloat* twl, int l, int m) { return twl[(m - 1) * 64 + l]; }
+#if MF_TW1_REGS
+#define mf_tw1(twl, l, m) (r.tw1[m])
+#else
 MVN_HD cfloat mf_tw1(const cfloat* twl, int l, int m) { return twl[448 + (m - 1) * 8 + (l & 7)]; }
+#endif
 #endif
 
 // ---- forward transform of a wave's line: registers -> LDS line, bins in the order q = 64 j + 8 k + a ----

@@ -1182,6 +1182,7 @@ def test_fused_middle_pass_on_the_line_layout_vs_oracle(emu, monkeypatch, shape,
     # lines along dim1 are contiguous, Nyquist bins packed into the DC column.  Odd / even / single-plane / deepest
     # instantiated PSF depths, lambda 0 and > 0, against the oracle; MVN_MID_FUSED=0 keeps the three-pass middle.
     monkeypatch.setenv("MVN_PAD_MODE", "none")
+    monkeypatch.setenv("MVN_MID_FUSED", "2")  # (by default only for volumes of at least three PSF depths of planes)
     emu.l.mvn_release_cached_engines()
     views, k1, k2, w, psi0 = _lines_case(shape, kshape)
     for lam in (0.0, 0.006):
@@ -1198,7 +1199,14 @@ def test_fused_middle_pass_on_the_line_layout_vs_oracle(emu, monkeypatch, shape,
         three = emu.gpu_deconvolve(psi0, h)
         assert emu.l.mvn_mid_fused_launch_count() == c0
         assert np.abs(three - got).max() <= 1e-5 * np.abs(got).max()
+        monkeypatch.setenv("MVN_MID_FUSED", "2")
+    if kshape[0] == 31:  # 40 planes at 31 taps: the default rule keeps the three passes
         monkeypatch.delenv("MVN_MID_FUSED")
+        emu.l.mvn_release_cached_engines()
+        c0 = emu.l.mvn_mid_fused_launch_count()
+        three = emu.gpu_deconvolve(psi0, h)
+        assert emu.l.mvn_mid_fused_launch_count() == c0
+        assert np.abs(three - got).max() <= 1e-5 * np.abs(got).max()
     emu.l.mvn_release_cached_engines()
 
 
@@ -1260,3 +1268,32 @@ def test_fused_middle_pass_in_the_simultaneous_loop(emu):
         assert np.abs(e.get_psi() - seq).max() <= 1e-5 * np.abs(seq).max()
     finally:
         e.close()
+
+
+def test_default_padding_policy_reaches_the_fused_middle_pass(emu):
+    # blocks whose rows and columns pad to 512 - 482 + 31 - 1 - run the fused middle pass under the library's DEFAULT
+    # policy (zero padding to FFT-friendly extents, dim0 exact under the direct leg): what a host program that sizes
+    # its blocks for it gets; oracle on hand-padded stacks, guard on
+    shape, ks = (12, 482, 482), (5, 31, 31)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, ks, seed=2)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    emu.l.mvn_release_cached_engines()
+    c0 = emu.l.mvn_mid_fused_launch_count()
+    got = emu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert emu.l.mvn_mid_fused_launch_count() - c0 == 2 * 2 * 2
+    ext, off = (16, 512, 512), (2, 15, 15)
+    sl = tuple(slice(o, o + s) for o, s in zip(off, shape))
+
+    def embed(x):
+        out = np.zeros(ext, np.float32)
+        out[sl] = x
+        return out
+
+    hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-4, 2)
+    orc.set_quotient_guard(True)
+    try:
+        ref = orc.cpu_deconvolve(embed(psi0), hp, 8)[sl]
+    finally:
+        orc.set_quotient_guard(False)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    emu.l.mvn_release_cached_engines()

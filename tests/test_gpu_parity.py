@@ -1526,7 +1526,7 @@ def test_default_policy_keeps_dim0_exact_under_the_direct_leg(gpu, orc, monkeypa
 
 
 def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
-    # (64, 512, 512) x 2 views x 31-plane PSFs: the shape class of the headline - planes of 512 x 512, where the
+    # (96, 512, 512) x 2 views x 31-plane PSFs: the shape class of the headline - planes of 512 x 512, where the
     # three middle passes run as ONE (csrc/mvn_mid_fused.hpp; round 3 / first half of round 4: the direct dim0 leg
     # between two dim1 passes).  Two runs from the same psi are bit-identical (no atomics, no order dependence), and
     # the result agrees to rounding with the three-pass middle (MVN_MID_FUSED=0: direct leg) and with the fused FFT
@@ -1534,7 +1534,7 @@ def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
     # kernels' A/B knobs once per process).
     import subprocess
     import sys
-    shape, V = (64, 512, 512), 2
+    shape, V = (96, 512, 512), 2
     from ref_fixtures import structured_views
     views, k1, k2, w, psi0 = structured_views(shape, V, (31, 9, 9), seed=3)
 
@@ -1560,7 +1560,7 @@ def test_headline_path_is_deterministic_and_matches_the_fft_leg(gpu):
             "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
             "from libmultiviewnative_amd import native\n"
             "from ref_fixtures import structured_views\n"
-            "g = native.lib(); shape, V = (64, 512, 512), 2\n"
+            "g = native.lib(); shape, V = (96, 512, 512), 2\n"
             "views, k1, k2, w, psi0 = structured_views(shape, V, (31, 9, 9), seed=3)\n"
             "e = g.engine(shape, V)\n"
             "[e.set_view(v, views[v], w[v], k1[v], k2[v]) for v in range(V)]\n"
@@ -1587,6 +1587,7 @@ def test_fused_middle_pass_on_the_line_layout_vs_oracle(gpu, orc, monkeypatch, s
     # these shapes).  Through the ABI call (pipelined staging: the form is decided from the kernels' extents before
     # the last view has arrived) and through a resident engine; MVN_MID_FUSED=0 = the three-pass middle.
     monkeypatch.setenv("MVN_PAD_MODE", "none")
+    monkeypatch.setenv("MVN_MID_FUSED", "2")  # (by default only for volumes of at least three PSF depths of planes)
     gpu.check(gpu.l.mvn_release_cached_engines())
     _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=61)
     k2 = [np.ascontiguousarray(k[::-1, :, :]) for k in k1]
@@ -1675,3 +1676,34 @@ def test_fused_middle_pass_in_the_simultaneous_loop(gpu, orc):
         assert np.array_equal(e.get_psi(), whole)
     finally:
         e.close()
+
+
+def test_default_padding_policy_reaches_the_fused_middle_pass(gpu, orc):
+    # blocks whose rows and columns pad to 512 - 482 + 31 - 1 - run the fused middle pass under the library's DEFAULT
+    # policy (zero padding to FFT-friendly extents, dim0 exact under the direct leg: inc/padd_utils.h:121-138 as the
+    # reference's GPU entry applies it): what a host program that sizes its blocks for it gets; oracle on hand-padded
+    # stacks, guard on
+    shape, ks = (40, 482, 482), (9, 31, 31)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, ks, seed=2)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 3)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    c0 = gpu.l.mvn_mid_fused_launch_count()
+    got = gpu.gpu_deconvolve(psi0, h, pad_mode=False)
+    assert gpu.l.mvn_mid_fused_launch_count() - c0 == 3 * 2 * 2
+    ext, off = (48, 512, 512), (4, 15, 15)
+    sl = tuple(slice(o, o + s) for o, s in zip(off, shape))
+
+    def embed(x):
+        out = np.zeros(ext, np.float32)
+        out[sl] = x
+        return out
+
+    hp = WorkspaceHolder([embed(v) for v in views], k1, k2, [embed(x) for x in w], 0.006, 1e-4, 3)
+    orc.set_quotient_guard(True)
+    try:
+        ref = orc.cpu_deconvolve(embed(psi0), hp, -1)[sl]
+    finally:
+        orc.set_quotient_guard(False)
+    mx, rms = rel_err(got, ref)
+    assert mx <= 1e-5 and rms <= 1e-6, (mx, rms)
+    gpu.check(gpu.l.mvn_release_cached_engines())

@@ -1315,6 +1315,16 @@ MVN_HD void fx_r2c_post(const RowsParams& P, long r0, cfloat* buf, const cfloat*
 // spec[plane][position][row of the plane]: the T rows of a tile are T neighbouring entries of H lines, one
 // 8-byte access per lane, T lanes per line (128 contiguous bytes for 16-row tiles).  Row `r0` of the launch is row
 // P.row_base + r0 of the volume; tiles never straddle planes (T divides the rows of a plane).
+// The line-layout side in 16-byte accesses (two neighbouring rows per lane) or 8-byte ones (one row per lane), per
+// epilogue: measured at 512^3 (tools/ab_libs.sh, profiles/r04_mid_fused.md) the fused divide gains 11 % with 16 bytes
+// (0.337 -> 0.299 ms), the plain r2c pass 6 %, the fused update loses 1.4 % (0.495 -> 0.502: three more streams).
+#ifndef MVN_FX_LINES_16B
+#define MVN_FX_LINES_16B -1  // -1: per epilogue; 0 / 1: all passes 8 / 16 bytes (A/B builds)
+#endif
+template <int EPI>
+constexpr bool fx_lines_wide() {
+  return MVN_FX_LINES_16B < 0 ? (EPI != MVN_EPI_UPDATE && EPI != MVN_EPI_DELTA) : MVN_FX_LINES_16B != 0;
+}
 template <int H>
 MVN_HD long fx_lines_base(const RowsParams& P, long r0) {
   const long R = P.row_base + r0;
@@ -1322,18 +1332,29 @@ MVN_HD long fx_lines_base(const RowsParams& P, long r0) {
   return z * (long)H * P.lines_d1 + (R - z * P.lines_d1);
 }
 
-template <int H, bool LINES = false>
+template <int H, bool LINES = false, bool W16 = true>
 MVN_HD void fx_r2c_store(const RowsParams& P, long r0, const cfloat* buf, int tid) {
   typedef FxRowsCfg<H> C;
   constexpr int TP = C::TP, NT = C::NT, U = C::U;
   if constexpr (LINES) {
     static_assert((C::T * H) % NT == 0, "line layout: whole sweeps");
     cfloat* dst = P.out_cplx + fx_lines_base<H>(P, r0);
+    if constexpr (W16) {
+      // two neighbouring rows per lane: one 16-byte global access, two 8-byte LDS accesses (the tile's pitch is odd)
 #pragma unroll
-    for (int u = 0; u < 2 * U; ++u) {
-      const int e = tid + u * NT;
-      const int rho = e % C::T, p = e / C::T;
-      dst[(long)p * P.lines_d1 + rho] = buf[fx_row<C::PAD>(p) * TP + rho];
+      for (int u = 0; u < U; ++u) {
+        const int e = tid + u * NT;
+        const int r2 = 2 * (e % (C::T / 2)), p = e / (C::T / 2);
+        const cfloat a = buf[fx_row<C::PAD>(p) * TP + r2], b = buf[fx_row<C::PAD>(p) * TP + r2 + 1];
+        *reinterpret_cast<qfloat*>(dst + (long)p * P.lines_d1 + r2) = qmake(a.x, a.y, b.x, b.y);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2 * U; ++u) {
+        const int e = tid + u * NT;
+        const int rho = e % C::T, p = e / C::T;
+        dst[(long)p * P.lines_d1 + rho] = buf[fx_row<C::PAD>(p) * TP + rho];
+      }
     }
     return;
   }
@@ -1361,7 +1382,7 @@ MVN_HD void fx_rows_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ctx& c
   MVN_PHASE(ctx, (fx_r2c_load_stage0<H>(P, r0, buf, tws, twr, tid)));
   fx_dif<H, T, TP, C::PAD, NT, -1, 1, C::TWT>(buf, tws, ctx);
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
-  MVN_PHASE(ctx, (fx_r2c_store<H, LINES>(P, r0, buf, tid)));
+  MVN_PHASE(ctx, (fx_r2c_store<H, LINES, fx_lines_wide<MVN_EPI_STORE>()>(P, r0, buf, tid)));
 }
 
 // compile-time-mode form of the fused pass's pair epilogue: the kernels are instantiated per
@@ -1381,12 +1402,20 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
   if constexpr (LINES) {
     // two 8-byte entries per register quad: sweep 2 u in .xy, sweep 2 u + 1 in .zw
     const cfloat* src = P.in_cplx + fx_lines_base<H>(P, r0);
+    if constexpr (fx_lines_wide<EPI>()) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e0 = tid + 2 * u * NT, e1 = e0 + NT;
-      const cfloat a = src[(long)(e0 / C::T) * P.lines_d1 + e0 % C::T];
-      const cfloat b = src[(long)(e1 / C::T) * P.lines_d1 + e1 % C::T];
-      r.v[u] = qmake(a.x, a.y, b.x, b.y);
+      for (int u = 0; u < U; ++u) {
+        const int e = tid + u * NT;
+        r.v[u] = *reinterpret_cast<const qfloat*>(src + (long)(e / (C::T / 2)) * P.lines_d1 + 2 * (e % (C::T / 2)));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e0 = tid + 2 * u * NT, e1 = e0 + NT;
+        const cfloat a = src[(long)(e0 / C::T) * P.lines_d1 + e0 % C::T];
+        const cfloat b = src[(long)(e1 / C::T) * P.lines_d1 + e1 % C::T];
+        r.v[u] = qmake(a.x, a.y, b.x, b.y);
+      }
     }
   } else {
 #pragma unroll
@@ -1422,11 +1451,21 @@ MVN_HD void fx_c2r_load(const RowsParams& P, long r0, cfloat* buf, cfloat* tws, 
   }
   if (!C::WALK) fx_rows_tables<H>(P, tws, twr, tid);
   if constexpr (LINES) {
+    if constexpr (fx_lines_wide<EPI>()) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e0 = tid + 2 * u * NT, e1 = e0 + NT;
-      buf[fx_row<C::PAD>(e0 / C::T) * TP + e0 % C::T] = cmake(r.v[u].x, r.v[u].y);
-      buf[fx_row<C::PAD>(e1 / C::T) * TP + e1 % C::T] = cmake(r.v[u].z, r.v[u].w);
+      for (int u = 0; u < U; ++u) {
+        const int e = tid + u * NT;
+        cfloat* q = buf + fx_row<C::PAD>(e / (C::T / 2)) * TP + 2 * (e % (C::T / 2));
+        q[0] = cmake(r.v[u].x, r.v[u].y);
+        q[1] = cmake(r.v[u].z, r.v[u].w);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e0 = tid + 2 * u * NT, e1 = e0 + NT;
+        buf[fx_row<C::PAD>(e0 / C::T) * TP + e0 % C::T] = cmake(r.v[u].x, r.v[u].y);
+        buf[fx_row<C::PAD>(e1 / C::T) * TP + e1 % C::T] = cmake(r.v[u].z, r.v[u].w);
+      }
     }
     return;
   }
@@ -1535,7 +1574,7 @@ MVN_HD void fx_rows_c2r_r2c_body(const RowsParams& P, long tile, cfloat* lds, Ct
 #if !(defined(MVN_EXPERIMENTS) && defined(MVN_EXP_SKIP_PREPOST))
   MVN_PHASE(ctx, (fx_r2c_post<H>(P, r0, buf, twr, tid)));
 #endif
-  MVN_PHASE(ctx, (fx_r2c_store<H, LINES>(P, r0, buf, tid)));
+  MVN_PHASE(ctx, (fx_r2c_store<H, LINES, fx_lines_wide<EPI>()>(P, r0, buf, tid)));
 }
 
 template <int H, int EPI, typename Ctx, bool LINES = false>

@@ -10,7 +10,7 @@
 //     spec[z][c][y]      z < d0 planes,  c < H columns (last-axis positions),  y < N1 rows of the plane
 // i.e. the lines along dim1 are contiguous (the row-major layout [z][y][c] keeps them C bins apart).  A workgroup
 // takes ONE column c and walks along dim0: a line (z, c, .) of N1 = 512 bins comes in, is transformed along dim1
-// (one line per wave, 8 bins per lane, radix 8 x 8 x 8 with two wave-private LDS exchanges), every bin goes through
+// (one line per wave, 8 bins per lane, radix 8 x 8 x 8 with two wave-private LDS exchanges and no workgroup barrier), every bin goes through
 // its K-tap filter along dim0 - the filter state (K taps, K inputs) lives in the registers of the ONE work item
 // that owns the bin for the whole walk -, the line is transformed back and stored.  31 lines of a column are the
 // window of the direct convolution: 124 KB, which is what the registers of one CU hold beside the code's own
@@ -22,14 +22,17 @@
 // the taps are stored in the same order (they go through the same forward code, MF_TAPS), and the inverse
 // transform undoes it: no permutation anywhere.
 //
-// Pipeline of a workgroup (8 waves, batches of 8 lines = 8 consecutive planes, one line per wave), iteration i:
-//     wave w:  inverse transform + store of line w of batch i - 1      (buffer B[(i + 1) & 1], line w)
-//              forward transform of line w of batch i + 1 -> LDS       (same buffer, same line: wave-private)
+// Pipeline of a workgroup (8 waves, batches of 8 lines = 8 consecutive planes, one line per wave), iteration i, on four
+// line buffers in the LDS (FW[2]: transformed lines, the filter's input; OU[2]: the filter's output):
+//     wave w:  transform back + store of line w of batch i - 1         (OU[(i - 1) & 1], line w: wave-private)
+//              forward transform of line w of batch i + 1 -> LDS        (FW[(i + 1) & 1], line w: wave-private)
 //              global loads of line w of batch i + 2 -> registers
-//     all:     filter step on the 8 lines of batch i, in place          (buffer B[i & 1]; work item q <-> bin q)
+//     all:     filter step on the 8 lines of batch i, FW[i & 1] -> OU[i & 1]   (work item q <-> bin q of every line)
 //     ONE workgroup barrier
-// The window is indexed with compile-time register numbers: KW = K rounded up to a multiple of 8 slots, the
-// filter code exists KW / 8 times (batch i uses variant i mod KW / 8), selected by a workgroup-uniform branch.
+// The two transforms of a wave are independent and run as stage pairs; the filter's lines are dealt out between a
+// pair's LDS requests and its arithmetic (mf_body).  The window is indexed with compile-time register numbers: KW = K
+// rounded up to a multiple of 8 slots, the filter code exists KW / 8 times per line (batch i uses variant i mod KW / 8),
+// selected by a workgroup-uniform branch.
 #pragma once
 
 #include <stdexcept>
@@ -47,9 +50,6 @@
 #define MF_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local")
 #else
 #define MF_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
-#endif
-#ifndef MF_TW_REGS
-#define MF_TW_REGS 0
 #endif
 
 #if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
@@ -102,11 +102,6 @@ struct MfRegs {
   cfloat w[mf_slots(K)];
   cfloat xr[8];   // the wave's line of the batch after next, as loaded (element l + 64 m in xr[m])
   cfloat t[8];    // a transform stage's values between its reads and its writes
-#if MF_TW_REGS
-  cfloat tw0[8], tw1[8];  // the lane's twiddles (A/B: registers instead of the LDS table)
-#elif MF_TW1_REGS
-  cfloat tw1[8];
-#endif
   cfloat bad;
   cfloat t2[8];   // ... of the forward transform that runs beside a transform back
   cfloat xn, xp;  // the filter's input of the next line (and, DC column, its partner bin), requested a line ahead
@@ -154,6 +149,9 @@ MVN_HD void mf_fetch(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int b
   const int n = batch * MF_LINES + wv;
   if (n >= nsteps) return;
   const cfloat* src = P.in + ((long)mf_in_plane(P, z0, n) * P.H + c) * MF_N1 + l;
+#if defined(MVN_EXPERIMENTS) && defined(MF_EXP_NOLOAD)  // timing experiment (probe builds only, WRONG results): what the loads cost
+  if (batch > 1) return;
+#endif
 #pragma unroll
   for (int m = 0; m < 8; ++m) r.xr[m] = src[64 * m];
 }
@@ -163,16 +161,6 @@ MVN_HD void mf_setup(const MidFusedParams& P, MfRegs<K>& r, int c, int z0, int n
   r.bad = cmake(0.f, 0.f);
   r.dcmode = MF_DC_NONE;
   r.qm = r.cpar = 0;
-#if MF_TW_REGS
-#pragma unroll
-  for (int m = 1; m < 8; ++m) {
-    r.tw0[m] = P.tw[(tid & 63) * m];
-    r.tw1[m] = P.tw[8 * (tid & 7) * m];
-  }
-#elif MF_TW1_REGS
-#pragma unroll
-  for (int m = 1; m < 8; ++m) r.tw1[m] = P.tw[8 * (tid & 7) * m];
-#endif
 #pragma unroll
   for (int j = 0; j < K; ++j) r.tap[j] = j < P.k ? P.taps[((long)mf_tap_plane(P, j) * P.H + c) * MF_N1 + tid] : cmake(0.f, 0.f);
 #pragma unroll
@@ -219,20 +207,8 @@ MVN_HD void mf_build_twiddles(const MidFusedParams& P, cfloat* twl, int tid) {
   }
 }
 // (fetched one by one where a stage multiplies: all seven up front cost 4 - 20 % of the kernel, as 16-byte pairs 4 %)
-#ifndef MF_TW1_REGS
-#define MF_TW1_REGS 0  // A/B: the seven stage-1 twiddles of a lane in registers (14 of them), stage 0's in the LDS
-#endif
-#if MF_TW_REGS
-#define mf_tw0(twl, l, m) (r.tw0[m])
-#define mf_tw1(twl, l, m) (r.tw1[m])
-#else
 MVN_HD cfloat mf_tw0(const cfloat* twl, int l, int m) { return twl[(m - 1) * 64 + l]; }
-#if MF_TW1_REGS
-#define mf_tw1(twl, l, m) (r.tw1[m])
-#else
 MVN_HD cfloat mf_tw1(const cfloat* twl, int l, int m) { return twl[448 + (m - 1) * 8 + (l & 7)]; }
-#endif
-#endif
 
 // ---- forward transform of a wave's line: registers -> LDS line, bins in the order q = 64 j + 8 k + a ----
 template <int K>
@@ -397,6 +373,9 @@ MVN_HD void mf_inv0_c_store(MfRegs<K>& r, const cfloat* twl, cfloat* dst, int ti
 #pragma unroll
   for (int m = 1; m < 8; ++m) r.t[m] = mf_cmulc(r.t[m], mf_tw0(twl, l, m));
   dftR<8, +1>(r.t);
+#if defined(MVN_EXPERIMENTS) && defined(MF_EXP_NOSTORE)  // timing experiment (probe builds only, WRONG results): what the stores cost
+  if (r.t[0].x == 12345.678f)
+#endif
 #pragma unroll
   for (int m = 0; m < 8; ++m) dst[l + 64 * m] = r.t[m];
 }
@@ -588,22 +567,12 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
   // Four line buffers: the forward transforms of batch i + 1 go to FW[(i + 1) & 1], the filter step of batch i reads
   // FW[i & 1] and writes OU[i & 1], the transforms back of batch i - 1 read OU[(i - 1) & 1].  A wave's forward and
   // backward transform of an iteration are then independent of each other (two lines, two register sets): their
-  // stages run in pairs, the LDS reads of a pair are requested together.
-  // MF_SCHED 0 (default): the lines of the filter step - pure arithmetic on other buffers - are dealt out between the
-  // transform stages, behind their LDS requests.  A/B forms (tools/mf_ab.sh; profiles/r04_mid_fused.md): 2 = every
-  // wave filters first and transforms second, 1 = the other way round, 3 = waves 0 .. 3 one way and waves 4 .. 7 -
-  // which share their SIMDs - the other way; as written (a two-pass loop around the blocks) those spill.
-#ifndef MF_SCHED
-#define MF_SCHED 0
-#endif
-#ifndef MF_PRIO_T
-#define MF_PRIO_T 2  // (A/B, with -DMF_PRIO: issue priority of a wave outside the filter step's lines)
-#endif
-#if defined(__HIPCC__) && !defined(MVN_HOST_EMU)
-  const int filter_first = MF_SCHED == 3 ? mvn_uniform((ctx.tid >> 8) & 1) : (MF_SCHED == 2);
-#else
-  const int filter_first = 1;
-#endif
+  // stages run in pairs (A, B, C), the LDS reads of a pair are requested together, and the lines of the filter step
+  // - arithmetic on other buffers - are dealt out between a pair's requests and its arithmetic.
+  // Orders that were tried and lost (profiles/r04_mid_fused.md): the filter step as one block in front of / behind the
+  // transforms (+3 .. +18 %, and the loop that selects the order per wave spills), the forward transform one stage
+  // behind the transform back (+8 %: a fourth stage in the batch's chain), the two halves of the CU's waves a third
+  // of a batch out of step (+6 %), a stepped schedule read from a per-wave table (290 spills).
   for (int i = -1; i <= nb; ++i) {
     const cfloat* fin = lds + (i & 1) * MF_BUF;
     cfloat* fout = lds + (2 + (i & 1)) * MF_BUF;
@@ -612,42 +581,14 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     const bool T1 = i >= 1, T2 = i + 1 < nb, F = i >= 0 && i < nb;
     const bool fill = i * MF_LINES + MF_LINES - 1 < K - 1;
     const int u = F ? i % (mf_slots(K) / 8) : 0;
-#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && defined(MF_PRIO)
-#define MF_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define MF_SETPRIO(p) (void)0
-#endif
 #define MF_FLINE(C)                                                                \
   if (F) {                                                                         \
-    MF_SETPRIO(0);                                                                 \
     MF_WPHASE(ctx, (mf_fline_dispatch<K, C, 0>(r, fin, fout, u, fill, dc, tid)));  \
-    MF_SETPRIO(MF_PRIO_T);                                                         \
   }
-#if MF_SCHED == 0
     if (F) {
       MF_WPHASE(ctx, (mf_fread<K>(r, fin, 0, dc, tid)));
     }
-#define MF_FLINE_IL(C) MF_FLINE(C)
-#else
-#define MF_FLINE_IL(C)
-#pragma nounroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if ((pass == 0) == (filter_first != 0)) {
-        if (F) {
-          MF_WPHASE(ctx, (mf_fread<K>(r, fin, 0, dc, tid)));
-        }
-        MF_FLINE(0) MF_FLINE(1) MF_FLINE(2) MF_FLINE(3) MF_FLINE(4) MF_FLINE(5) MF_FLINE(6) MF_FLINE(7)
-        continue;
-      }
-#endif
-    // Stages A, B, C: the transform back and the forward transform side by side, their reads requested together.
-    // (MF_FWD_SHIFT=1, A/B: the forward transform one stage behind, in B, C, D - so that it does not wait for its
-    // line, and with it for the global stores of the batch before, right behind the barrier: +8 %, a fourth
-    // stage in the iteration's chain costs more than that wait.)
-#ifndef MF_FWD_SHIFT
-#define MF_FWD_SHIFT 0
-#endif
-    // stage A
+    // stage A: first stage back (reads the line) | first forward stage (reads the registers loaded ahead)
     if (T1) {
       if (dc) {
         MF_WPHASE(ctx, (mf_inv2_r_dc<K>(r, inv, tid)));
@@ -655,12 +596,10 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
         MF_WPHASE(ctx, (mf_inv2_r<K>(r, inv, tid)));
       }
     }
-#if !MF_FWD_SHIFT
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
     }
-#endif
-    MF_FLINE_IL(0)
+    MF_FLINE(0)
     if (T1) {
       MF_WPHASE(ctx, (dftR<8, +1>(r.t), mf_inv2_b<K>(r, inv, tid)));
     }
@@ -668,67 +607,36 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_r<K>(r, inv, tid)));
     }
-#if MF_FWD_SHIFT
-    if (T2) {
-      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
-    }
-#else
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_r2<K>(r, fwd, tid)));
     }
-#endif
-    MF_FLINE_IL(1)
-    MF_FLINE_IL(2)
+    MF_FLINE(1)
+    MF_FLINE(2)
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid)));
     }
-#if !MF_FWD_SHIFT
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
     }
-#endif
     // stage C
     if (T1) {
       MF_WPHASE(ctx, (mf_inv0_r<K>(r, inv, tid)));
     }
     if (T2) {
-#if MF_FWD_SHIFT
-      MF_WPHASE(ctx, (mf_fwd1_r2<K>(r, fwd, tid)));
-#else
       MF_WPHASE(ctx, (mf_fwd2_r2<K>(r, fwd, tid)));
-#endif
     }
-    MF_FLINE_IL(3)
-    MF_FLINE_IL(4)
+    MF_FLINE(3)
+    MF_FLINE(4)
     if (T1) {
       MF_WPHASE(ctx, (mf_store_line_c<K>(P, r, twl, c, z0, nout, i - 1, tid)));
     }
     if (T2) {
-#if MF_FWD_SHIFT
-      MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
-#else
-      MF_WPHASE(ctx, (dftR<8, -1>(r.t2), mf_fwd2_b2<K>(r, fwd, tid)));
-#endif
-    }
-    // stage D
-#if MF_FWD_SHIFT
-    if (T2) {
-      MF_WPHASE(ctx, (mf_fwd2_r2<K>(r, fwd, tid)));
-    }
-#endif
-    MF_FLINE_IL(5)
-    MF_FLINE_IL(6)
-#if MF_FWD_SHIFT
-    if (T2) {
       MF_WPHASE(ctx, (dftR<8, -1>(r.t2), mf_fwd2_b2<K>(r, fwd, tid)));
     }
-#endif
-    MF_FLINE_IL(7)
-#if MF_SCHED != 0
-    }
-#endif
+    MF_FLINE(5)
+    MF_FLINE(6)
+    MF_FLINE(7)
 #undef MF_FLINE
-#undef MF_FLINE_IL
     MVN_PHASE(ctx, (void)0);
   }
   MVN_PHASE_NOSYNC(ctx, (mf_report<K>(P, r)));
@@ -739,13 +647,6 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
 // workgroup.
 MVN_HD void mf_taps_load(const MidFusedParams& P, MfRegs<1>& r, long batch, int c, int tid) {
   const int l = tid & 63, z = (int)batch * MF_LINES + (tid >> 6);
-#if MF_TW_REGS
-#pragma unroll
-  for (int m = 1; m < 8; ++m) {
-    r.tw0[m] = P.tw[l * m];
-    r.tw1[m] = P.tw[8 * (l & 7) * m];
-  }
-#endif
   if (z >= P.d0) return;
   const cfloat* src = P.in + ((long)z * P.H + c) * MF_N1 + l;
 #pragma unroll

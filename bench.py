@@ -251,18 +251,9 @@ def exact_halo_mode(lib, devices, shape, psf_edge, n_views, steps, warmup, check
            "devices": list(devices), "value": round(steps / (ms * 1e-3), 4), "unit": "iterations/s",
            "ms_per_step": round(ms / steps, 4), "steps": steps, "warmup": warmup,
            "psi_finite_positive": bool(np.isfinite(got).all() and (got > 0).all())}
-    # (the slabs run the Nyquist layout the whole volume has on one device and its THREE middle passes - they
-    # exchange halo planes between them -: the same arithmetic as the one-device engine with MVN_MID_FUSED=0, bit for
-    # bit; the fused middle pass a 512^3 engine takes by default differs from it by rounding, see `parity` of the line)
-    saved = os.environ.get("MVN_MID_FUSED")
-    os.environ["MVN_MID_FUSED"] = "0"  # (read when an engine is made)
-    try:
-        e = lib.engine(shape, n_views, device=check_device)
-    finally:
-        if saved is None:
-            os.environ.pop("MVN_MID_FUSED", None)
-        else:
-            os.environ["MVN_MID_FUSED"] = saved
+    # (the slabs run the layout and the middle - fused on planes of 512 x 512 - the whole volume has on one device: the
+    # same arithmetic, bit for bit)
+    e = lib.engine(shape, n_views, device=check_device)
     try:
         for v in range(n_views):
             e.set_view(v, views[v], w, k1s[v], k2s[v])
@@ -275,7 +266,7 @@ def exact_halo_mode(lib, devices, shape, psf_edge, n_views, steps, warmup, check
         one = e.get_psi()
     finally:
         e.close()
-    out["parity"] = {"case": "psi after %d sweeps vs the one-device engine's sequential sweep (three-pass middle)" % (warmup + steps),
+    out["parity"] = {"case": "psi after %d sweeps vs the one-device engine's sequential sweep" % (warmup + steps),
                      "bit_equal": bool(np.array_equal(got, one)),
                      "max_rel": float(np.abs(got.astype(np.float64) - one).max() / np.abs(one).max())}
     return out

@@ -422,7 +422,8 @@ bool Plan3D::lines_capable() const {
 }
 
 void Plan3D::mid_fused(const cfloat* in, cfloat* out, const cfloat* taps, int k, int kd, unsigned* poison,
-                       unsigned poison_epoch, be::stream_t s, Profiler* prof) const {
+                       unsigned poison_epoch, be::stream_t s, Profiler* prof, int zbeg, int zcount, int n_peers,
+                       unsigned* const* peers) const {
   if (!lines_capable()) throw std::logic_error("mvn: this shape has no fused middle pass");
   MidFusedParams p;
   std::memset(&p, 0, sizeof(p));
@@ -440,6 +441,10 @@ void Plan3D::mid_fused(const cfloat* in, cfloat* out, const cfloat* taps, int k,
   p.packed = 1;
   p.poison = poison;
   p.poison_epoch = poison_epoch;
+  p.zbeg = zbeg;
+  p.zcount = zcount;
+  p.n_peers = n_peers;
+  p.poison_peers = peers;
   ProfScope ps(prof, KK_MID_FUSED, s);
   be::launch_mid_fused(p, s);
 }
@@ -1120,7 +1125,9 @@ bool Engine::would_be_lines(const int* kdims) {
 // spectrum).  Decided per iterate() call, behind decide_layout().
 void Engine::decide_lines() {
   const bool was = lines_last_sweep_;
-  bool all = lines_capable_ && !halo_fn_ && halo_planes_ == 0 && !views_.empty();
+  bool all = lines_capable_ && !views_.empty();
+  if (halo_fn_ || halo_planes_ > 0)  // slabs: the common decision of whoever drives them, on plane ranges
+    all = all && halo_fn_ && lines_override_ == 1 && halo_ranged() && halo_nyq_aware_;
   if (all) {
     if (pipelined_) {
       all = lines_hint_;
@@ -1135,7 +1142,7 @@ void Engine::decide_lines() {
 }
 
 // the three middle passes of convolution i as ONE: work_ -> work2_ (line layout), the volumes swap roles
-void Engine::mid_fused_conv(const ViewSlot& s, int i, Profiler* prof) {
+void Engine::mid_fused_conv(const ViewSlot& s, int i, Profiler* prof, int zbeg, int zcount) {
   if (!s.taps_l_ok[i] || !s.tap_k[i]) throw std::logic_error("mvn: fused middle pass with a kernel that is not in its form");
   ensure_work2();
   if (++epoch_ == 0x7fffffffu) {
@@ -1144,7 +1151,7 @@ void Engine::mid_fused_conv(const ViewSlot& s, int i, Profiler* prof) {
   }
   armed_epoch_ = epoch_;
   plan_->mid_fused((const cfloat*)work_, (cfloat*)work2_, (const cfloat*)s.taps_l[i], s.tap_k[i], s.tap_kd[i], poison_,
-                   epoch_, stream_, prof);
+                   epoch_, stream_, prof, zbeg, zcount, (int)poison_peers_.size(), (unsigned* const*)(poison_own_ + 16));
   std::swap(work_, work2_);
   std::swap(work_nyq_, work2_nyq_);
 }
@@ -1166,8 +1173,38 @@ bool Engine::direct_ok_for(int k0, int d0, int d1, int d2) {
 void Engine::middle(const ViewSlot& s, int i, Profiler* prof, SideStream* side, const RowsProducer* produce) {
   const Plan3D& P = *plan_;
   if (lines_) {
-    if (produce && *produce) (*produce)(0, -1);
-    mid_fused_conv(s, i, prof);
+    if (!halo_fn_) {
+      if (produce && *produce) (*produce)(0, -1);
+      mid_fused_conv(s, i, prof);
+      return;
+    }
+    // Halo mode on the line layout: the first and last H planes of the slab are the neighbours'.  The last-axis pass
+    // that produces this convolution's input runs on the own planes [H, d0 - H) - the H planes at either end of them
+    // FIRST, then the call that lets the neighbours pull them (planes are contiguous in the line layout as they are
+    // in the row-major one), then the interior beside the copies -, the second call waits for the halos, and ONE
+    // middle pass walks every column from plane 0 to produce the own planes (it never wraps: its window fills on
+    // the lower halo).  Same calls, same order as the three-pass form below.
+    const int H = halo_planes_, own = P.L.d0 - 2 * H, view = (int)(&s - views_.data());
+    const long d1 = P.L.d1;
+    auto rows = [&](int z0, int nz) {
+      if (produce && *produce) (*produce)((long)z0 * d1, (long)nz * d1);
+    };
+    auto call = [&](int what) {
+      if (halo_drain_) be::stream_sync(stream_);
+      halo_fn_(halo_user_, work_, view, what);
+    };
+    if (produce && boundary_first()) {
+      rows(H, H);
+      rows(own, H);
+      call(i);
+      rows(2 * H, own - 2 * H);
+    } else {
+      rows(H, own);
+      call(i);
+    }
+    if (halo_split_) call(i + 4);
+    mid_fused_conv(s, i, prof, H, own);
+    if (halo_post_) call(i + 2);
     return;
   }
   // One launch chain on stream_ - dim1 forward, direct leg, dim1 inverse, three launches - wherever the Nyquist bins

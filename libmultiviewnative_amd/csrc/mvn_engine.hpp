@@ -135,8 +135,10 @@ class Plan3D {
   bool lines_capable() const;
   // dim1 forward + K-tap direct convolution along dim0 + dim1 inverse, `in` -> `out` (both in the line layout);
   // taps: [kd][C][d1] as prepared by taps_to_lines()
+  // zcount > 0: the output planes [zbeg, zbeg + zcount) only (slabs with halo planes); peers: further poison words
   void mid_fused(const cfloat* in, cfloat* out, const cfloat* taps, int k, int kd, unsigned* poison,
-                 unsigned poison_epoch, be::stream_t s, Profiler* prof = nullptr) const;
+                 unsigned poison_epoch, be::stream_t s, Profiler* prof = nullptr, int zbeg = 0, int zcount = 0,
+                 int n_peers = 0, unsigned* const* peers = nullptr) const;
   // PSF planes after the last-axis pass (line layout, this plan = the small plan of the tap arrays) -> transformed
   // along dim1 into the bin order mid_fused() filters in; in place
   void taps_to_lines(cfloat* taps, be::stream_t s) const;
@@ -320,7 +322,7 @@ class Engine {
     if (!plan_->nyq_rides()) layout_override_ = 1;  // (run-time-radix dim1 kernels carry no riders)
   }
   // input of the dim0 leg in flight: its Nyquist plane (nullptr in the packed layout); valid inside the hook
-  void* leg_input_nyq() const { return packed_ ? nullptr : (void*)work_nyq_; }
+  void* leg_input_nyq() const { return (packed_ || lines_) ? nullptr : (void*)work_nyq_; }
   // The poison word (mvn_dim0_direct.hpp, EpilogueParams::poison): a direct dim0 leg that met a non-finite input
   // stores its epoch there.  poison_ptr(): the device word; bind_poison(): use caller-owned device memory (4 bytes,
   // zeroed) instead, e.g. a torch tensor a collective can MAX-reduce in place; poison_get() drains the stream and
@@ -358,6 +360,10 @@ class Engine {
   // the call will (pipelined calls: the loop starts before the last view has been staged)
   bool would_be_lines(const int* kdims);
   void set_all_lines_hint(bool all) { lines_hint_ = all; }
+  // Halo mode (slabs of one volume): the slabs must all run the same middle - they exchange planes of its input -, so
+  // whoever drives them decides for all of them (mvn_multi.cpp): on = the fused middle pass where this slab has it.
+  // A hook set without this call keeps the three passes.
+  void set_lines_in_halo_mode(bool on) { lines_override_ = on ? 1 : 0; }
   bool lines_in_use() const { return lines_; }
   // a cached engine starts every ABI call from a clean per-call state
   void begin_call() {
@@ -422,7 +428,8 @@ class Engine {
   bool lines_forced_ = false;    // MVN_MID_FUSED=2: whenever the shape has the pass, however few planes
   bool lines_worth(int k0) const;
   void decide_lines();
-  void mid_fused_conv(const ViewSlot& s, int i, Profiler* prof);
+  void mid_fused_conv(const ViewSlot& s, int i, Profiler* prof, int zbeg = 0, int zcount = 0);
+  int lines_override_ = -1;  // halo mode: -1 = three-pass middle (a hook of unknown kind), 0 / 1 = the slabs' common decision
   halo_fn_t halo_fn_ = nullptr;
   void* halo_user_ = nullptr;
   bool halo_drain_ = true, halo_post_ = false, halo_split_ = false, halo_nyq_aware_ = false;

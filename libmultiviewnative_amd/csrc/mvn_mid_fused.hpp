@@ -87,9 +87,14 @@ struct MidFusedParams {
   int mode;            // MF_CONV, or MF_TAPS: forward transform only, bins stored in the kernel's order (PSF prep)
   int packed;          // column 0 holds DC + i Nyquist of every row (RowsParams::nyq_packed), in the volume and in the
                        // taps: see "packed DC column" below
-  // non-finite inputs: as Dim0DirectParams
+  // zcount > 0: only the output planes [zbeg, zbeg + zcount) are produced, every column as one piece (a slab whose
+  // first and last h planes are halo planes: zbeg = h, zcount = d0 - 2 h, and the walk never wraps); 0: all d0 planes
+  int zbeg, zcount;
+  // non-finite inputs: as Dim0DirectParams (poison_peers: the other slabs' words)
   unsigned* poison;
   unsigned poison_epoch;
+  int n_peers;
+  unsigned* const* poison_peers;
 };
 enum { MF_CONV = 0, MF_TAPS = 1 };
 enum { MF_DC_NONE = 0, MF_DC_LOW = 1, MF_DC_HIGH = 2, MF_DC_SELF = 3 };  // a work item's bin in the packed DC column
@@ -108,14 +113,17 @@ struct MfRegs {
   int dcmode, qm, cpar;  // packed DC column (see below): the bin's kind, its partner bin, the lane's partner offset
 };
 
-inline long mf_pieces(const MidFusedParams& P) { return P.seg > 0 ? (P.d0 + P.seg - 1) / P.seg : 1; }
+inline long mf_pieces(const MidFusedParams& P) { return (P.seg > 0 && P.zcount <= 0) ? (P.d0 + P.seg - 1) / P.seg : 1; }
 inline long mf_blocks(const MidFusedParams& P) { return P.mode == MF_TAPS ? (long)P.H * ((P.d0 + MF_LINES - 1) / MF_LINES) : (long)P.H * mf_pieces(P); }
 
 // the job of workgroup `block`: column c, first output plane z0, output planes nout
 MVN_HD void mf_job(const MidFusedParams& P, long block, int& c, int& z0, int& nout) {
   const long piece = block / P.H;
   c = (int)(block - piece * P.H);
-  if (P.seg > 0) {
+  if (P.zcount > 0) {
+    z0 = P.zbeg;
+    nout = P.zcount;
+  } else if (P.seg > 0) {
     z0 = (int)(piece * P.seg);
     nout = P.d0 - z0 < P.seg ? P.d0 - z0 : P.seg;
   } else {
@@ -133,6 +141,9 @@ inline void mf_check(const MidFusedParams& P) {
   const bool taps_mode = P.mode == MF_TAPS;
   if (!P.in || !P.out || !P.tw || P.d0 < 1 || P.H < 1 || (long)P.d0 * P.H * MF_N1 >= (1L << 31) * 4 || P.seg < 0)
     throw std::invalid_argument("mvn: fused middle pass: bad arguments");
+  if (P.zcount < 0 || P.zbeg < 0 || P.zbeg + P.zcount > P.d0 || P.n_peers < 0 || P.n_peers > MVN_D0_MAX_PEERS ||
+      (P.n_peers > 0 && !P.poison_peers))
+    throw std::invalid_argument("mvn: fused middle pass: bad plane range or peers");
   if (!taps_mode && (!P.taps || P.in == P.out || P.k < 1 || mvn_dim0_taps_template(P.k) > 31 || P.h != P.k / 2 || P.kd < P.k))
     throw std::invalid_argument("mvn: fused middle pass called outside its range");
 }
@@ -546,7 +557,10 @@ MVN_HD void mf_inv2_r_dc(MfRegs<K>& r, const cfloat* buf, int tid) {
 
 template <int K>
 MVN_HD void mf_report(const MidFusedParams& P, const MfRegs<K>& r) {
-  if ((r.bad.x != 0.f || r.bad.y != 0.f) && P.poison) *P.poison = P.poison_epoch;  // (NaN != 0)
+  if (r.bad.x != 0.f || r.bad.y != 0.f) {  // (NaN != 0)
+    if (P.poison) *P.poison = P.poison_epoch;
+    for (int i = 0; i < P.n_peers; ++i) *P.poison_peers[i] = P.poison_epoch;
+  }
 }
 
 template <int K, typename Ctx>

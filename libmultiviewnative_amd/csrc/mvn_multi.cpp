@@ -300,6 +300,15 @@ void HaloGroup::load(const imageType* psi, const workspace& input, const shape_t
     }
     e.set_psi(psi + first);
   });
+  // the slabs exchange planes of the middle's input: all of them take the fused middle pass (mvn_mid_fused.hpp), or none
+  bool lines = true;
+  for (int r = 0; r < P && lines; ++r) {
+    be::set_device(slabs_[(size_t)r].dev);
+    for (int v = 0; v < V_ && lines; ++v)
+      lines = slabs_[(size_t)r].eng->would_be_lines(input.data_[v].kernel1_dims_) &&
+              slabs_[(size_t)r].eng->would_be_lines(input.data_[v].kernel2_dims_);
+  }
+  for (int r = 0; r < P; ++r) slabs_[(size_t)r].eng->set_lines_in_halo_mode(lines);
   loaded_ = true;
 }
 

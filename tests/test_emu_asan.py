@@ -28,9 +28,11 @@ def test_fixed_and_wave_row_kernels_under_asan():
     env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, MVN_EMU_SO=ASAN_SO,
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     # every compile-time specialised length (power-of-two, mixed-radix, long rows, split-window), the
-    # wave-row passes and the direct dim0 leg (all tap counts, packed and split Nyquist); -p no:cacheprovider: the child must not fight the parent over .pytest_cache
+    # wave-row passes, the direct dim0 leg (all tap counts, packed and split Nyquist) and the fused middle pass with the
+    # line-layout last-axis passes (its LDS line buffers are a host vector here); -p no:cacheprovider: the child must not fight the parent over .pytest_cache
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_emu_engine.py"), "-q", "-x",
-                        "-p", "no:cacheprovider", "-k", "mixed_radix or wave_row or long_rows or fixed or direct_dim0"],
+                        "-p", "no:cacheprovider", "-k", "mixed_radix or wave_row or long_rows or fixed or direct_dim0 or fused_middle_pass_in_the_simultaneous "
+                              "or default_padding_policy_reaches or slabs_run_the_fused"],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     tail = r.stdout[-3000:] + r.stderr[-3000:]
     assert r.returncode == 0, tail

@@ -1297,3 +1297,34 @@ def test_default_padding_policy_reaches_the_fused_middle_pass(emu):
         orc.set_quotient_guard(False)
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     emu.l.mvn_release_cached_engines()
+
+
+@pytest.mark.parametrize("devices,emu_devices", [("0,0", None), ("0,1,0", "2")])
+def test_slabs_run_the_fused_middle_pass(emu, monkeypatch, devices, emu_devices):
+    # MVN_DEVICES on planes of 512 x 512: the slabs exchange halo planes of the MIDDLE's input, so they all take the
+    # fused middle pass or none does (HaloGroup::load decides; Engine::set_lines_in_halo_mode) - last-axis pass on the
+    # boundary planes first, the neighbours pull them, ONE middle pass per convolution walks every column from the
+    # lower halo to the upper one.  Bit-equal to the one-device call, the oracle's flood through an Inf voxel.
+    if emu_devices:
+        monkeypatch.setenv("MVN_EMU_DEVICES", emu_devices)
+    shape = (48, 512, 512)
+    views, k1, k2, w, psi0 = _lines_case(shape, (5, 3, 3))
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    emu.l.mvn_release_cached_engines()
+    try:
+        single = emu.gpu_deconvolve(psi0, h)
+        monkeypatch.setenv("MVN_DEVICES", devices)
+        before, c0 = emu.l.mvn_multi_device_calls(), emu.l.mvn_mid_fused_launch_count()
+        multi = emu.gpu_deconvolve(psi0, h)
+        assert emu.l.mvn_multi_device_calls() == before + 1
+        assert emu.l.mvn_mid_fused_launch_count() - c0 == 2 * 2 * 2 * len(devices.split(","))
+        assert np.array_equal(multi, single)
+        bad = psi0.copy()
+        bad[30, 5, 5] = np.inf
+        assert np.array_equal(emu.gpu_deconvolve(bad, h), orc.cpu_deconvolve(bad, h, 8), equal_nan=True)
+        monkeypatch.delenv("MVN_DEVICES")
+        ref = orc.cpu_deconvolve(psi0, h, 8)
+        assert np.abs(single - ref).max() <= 1e-5 * np.abs(ref).max()
+    finally:
+        monkeypatch.delenv("MVN_DEVICES", raising=False)
+        emu.l.mvn_release_cached_engines()

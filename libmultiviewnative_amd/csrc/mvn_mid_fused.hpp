@@ -109,7 +109,10 @@ struct MfRegs {
   cfloat t[8];    // a transform stage's values between its reads and its writes
   cfloat bad;
   cfloat t2[8];   // ... of the forward transform that runs beside a transform back
-  cfloat xn, xp;  // the filter's input of the next line (and, DC column, its partner bin), requested a line ahead
+  // the filter's input of the next line (and, DC column, its partner bin), requested a line ahead.  Two of each, lines
+  // taking turns: the request for line C + 1 is issued in front of line C's arithmetic, OUTSIDE the branches that select
+  // the line's variant (see MF_FLINE in mf_body)
+  cfloat xn[2], xp[2];
   int dcmode, qm, cpar;  // packed DC column (see below): the bin's kind, its partner bin, the lane's partner offset
 };
 
@@ -273,6 +276,9 @@ MVN_HD void mf_fwd1_c2(MfRegs<K>& r, const cfloat* twl, int tid) {
 }
 template <int K>
 MVN_HD void mf_fwd1_b2(const MfRegs<K>& r, cfloat* buf, int tid) {
+#if defined(MVN_EXPERIMENTS) && defined(MF_EXP_NO_S2)  // timing experiment (probe builds only, WRONG results): the exchange between stages 1 and 2 left out
+  if (tid >= 0) return;
+#endif
   const int wv = tid >> 6, l = tid & 63;
   cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
 #pragma unroll
@@ -280,6 +286,9 @@ MVN_HD void mf_fwd1_b2(const MfRegs<K>& r, cfloat* buf, int tid) {
 }
 template <int K>
 MVN_HD void mf_fwd2_r2(MfRegs<K>& r, const cfloat* buf, int tid) {
+#if defined(MVN_EXPERIMENTS) && defined(MF_EXP_NO_S2)  // timing experiment (probe builds only, WRONG results): the exchange between stages 1 and 2 left out
+  if (tid >= 0) return;
+#endif
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + 9 * (l & 7);
 #pragma unroll
@@ -339,6 +348,9 @@ MVN_HD void mf_inv2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
 }
 template <int K>
 MVN_HD void mf_inv2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
+#if defined(MVN_EXPERIMENTS) && defined(MF_EXP_NO_S2)  // timing experiment (probe builds only, WRONG results): the exchange between stages 1 and 2 left out
+  if (tid >= 0) return;
+#endif
   const int wv = tid >> 6, l = tid & 63;
   cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + 9 * (l & 7);
 #pragma unroll
@@ -346,6 +358,9 @@ MVN_HD void mf_inv2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
 }
 template <int K>
 MVN_HD void mf_inv1_r(MfRegs<K>& r, const cfloat* buf, int tid) {
+#if defined(MVN_EXPERIMENTS) && defined(MF_EXP_NO_S2)  // timing experiment (probe builds only, WRONG results): the exchange between stages 1 and 2 left out
+  if (tid >= 0) return;
+#endif
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* p = buf + wv * MF_PITCH + 72 * (l >> 3) + (l & 7);
 #pragma unroll
@@ -464,16 +479,45 @@ MVN_HD void mf_setup_dc(const MidFusedParams& P, MfRegs<K>& r, int tid) {
 // U = (batch mod KW / 8): step n = 8 batch + C fills slot 8 U + C; tap j multiplies the input of step n - j.
 // FILL: the first K - 1 steps of a walk only fill the window.  The input of a line is requested one line ahead
 // (r.xn, in the DC column r.xp as well).
+// MF_READ_AHEAD: the request for line C + 1 in front of line C, in code every variant of the line shares.  Issued
+// inside the variants (behind line C's last multiply-add), each variant's read was a different instruction, the value
+// a merge of them: the compiler read into a scratch register and waited for it at the end of every variant - a whole
+// LDS latency per line, 8 per batch (ISA of the round's first build; 0 restores that form for the comparison).
+#ifndef MF_READ_AHEAD
+#define MF_READ_AHEAD 1
+#endif
+#ifndef MF_ALWAYS_TRANSFORM
+#define MF_ALWAYS_TRANSFORM 1
+#endif
+#ifndef MF_A_ORDER
+#define MF_A_ORDER 0
+#endif
+// Issue priorities within a batch (device only).  A SIMD's two waves - w and w + 4 of the workgroup - are served oldest
+// first: wave w runs ahead (good: its transform stages wait for the LDS while wave w + 4 still multiplies), reaches the
+// batch's barrier ~3000 cycles early, and wave w + 4 finishes alone at the pace of one wave (shader-clock stamps,
+// profiles/r04_mid_fused.md).  Mode 3 keeps the hardware's order up to point MF_PRIO_SWITCH of the batch (the numbers
+// of the MF_STAMP points) and raises the younger wave from there: both reach the barrier together.  0: none;
+// 1, 2: earlier experiments (the younger wave always ahead; turns line by line) - no gain.
+#ifndef MF_FETCH_POINT
+#define MF_FETCH_POINT 1
+#endif
+#ifndef MF_PRIO_MODE
+#define MF_PRIO_MODE 3
+#endif
+#ifndef MF_PRIO_SWITCH
+#define MF_PRIO_SWITCH 5
+#endif
 template <int K>
 MVN_HD void mf_fread(MfRegs<K>& r, const cfloat* in, int c, bool dc, int tid) {
-  r.xn = in[c * MF_PITCH + tid];
-  if (dc) r.xp = in[c * MF_PITCH + r.qm];
+  r.xn[c & 1] = in[c * MF_PITCH + tid];
+  if (dc) r.xp[c & 1] = in[c * MF_PITCH + r.qm];
 }
 template <int K>
-MVN_HD cfloat mf_filter_input(MfRegs<K>& r, bool dc) {
-  cfloat x = r.xn;
+MVN_HD cfloat mf_filter_input(MfRegs<K>& r, int c, bool dc) {
+  cfloat x = r.xn[c & 1];
   if (dc) {
-    const cfloat lo = mf_herm0(x, r.xp), hi = mf_hermh(r.xp, x);
+    const cfloat xp = r.xp[c & 1];
+    const cfloat lo = mf_herm0(x, xp), hi = mf_hermh(xp, x);
     x = r.dcmode == MF_DC_LOW ? lo : (r.dcmode == MF_DC_HIGH ? hi : x);
   }
   return x;
@@ -482,8 +526,10 @@ template <int K, int U, int C, bool FILL>
 MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc, int tid) {
   constexpr int KW = mf_slots(K), S = 8 * U + C;
   if (FILL) {
-    r.w[S] = mf_filter_input<K>(r, dc);
+    r.w[S] = mf_filter_input<K>(r, C, dc);
+#if !MF_READ_AHEAD
     if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
+#endif
     return;
   }
   // OLDEST taps first: they multiply values that have sat in the registers for up to K steps.  The line's own input
@@ -504,7 +550,7 @@ MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc,
     else
       mvn_cmac2(a1[ch], a2[ch], r.w[(S - j + 2 * KW) % KW], r.tap[j]);
   }
-  const cfloat x = mf_filter_input<K>(r, dc);
+  const cfloat x = mf_filter_input<K>(r, C, dc);
   if (K <= NC)  // (chain 0 holds tap 0 alone)
     mvn_cmul2(a1[0], a2[0], x, r.tap[0]);
   else
@@ -516,11 +562,19 @@ MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc,
     s2 = cadd(s2, a2[ch]);
   }
   r.w[S] = x;
+#if !MF_READ_AHEAD
   if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
+#endif
   r.bad = mvn_dim0_track(r.bad, x);
   cfloat o = cadd_i<+1>(s1, s2);
   if (dc) o = r.dcmode == MF_DC_SELF ? cmake(s1.x, s2.y) : o;
   out[C * MF_PITCH + tid] = o;
+}
+template <int K, int C>
+MVN_HD void mf_fread_ahead(MfRegs<K>& r, const cfloat* in, bool dc, int tid) {
+#if MF_READ_AHEAD
+  if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
+#endif
 }
 template <int K, int C, int U>
 MVN_HD void mf_fline_dispatch(MfRegs<K>& r, const cfloat* in, cfloat* out, int u, bool fill, bool dc, int tid) {
@@ -539,12 +593,12 @@ MVN_HD void mf_fline_dispatch(MfRegs<K>& r, const cfloat* in, cfloat* out, int u
 // the first stage of the transform back reads the wave's line of filter outputs; in the DC column it reads the
 // partners of its bins as well and puts the two Hermitian halves together
 template <int K>
-MVN_HD void mf_inv2_r_dc(MfRegs<K>& r, const cfloat* buf, int tid) {
+MVN_HD void mf_inv2_fix_dc(MfRegs<K>& r, const cfloat* buf, int tid) {  // behind mf_inv2_r: r.t holds the wave's own bins
   const int wv = tid >> 6, l = tid & 63;
   const cfloat* line = buf + wv * MF_PITCH;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const cfloat o = line[64 * m + l];
+    const cfloat o = r.t[m];
     const cfloat p = line[(64 * (7 - m) + r.cpar) & (MF_N1 - 1)];
     // m < 4: frequencies below 256 (own = R0, partner = RH); m > 4: above (own = RH, partner = R0); m = 4: above,
     // but lane 0 (f = 256) - like lane 0 of m = 0 (f = 0) - holds a pair that is complete as it is
@@ -553,6 +607,11 @@ MVN_HD void mf_inv2_r_dc(MfRegs<K>& r, const cfloat* buf, int tid) {
     if (m == 0 || m == 4) v = l == 0 ? o : v;
     r.t[m] = v;
   }
+}
+template <int K>
+MVN_HD void mf_inv2_r_dc(MfRegs<K>& r, const cfloat* buf, int tid) {
+  mf_inv2_r<K>(r, buf, tid);
+  mf_inv2_fix_dc<K>(r, buf, tid);
 }
 
 template <int K>
@@ -587,36 +646,126 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
   // transforms (+3 .. +18 %, and the loop that selects the order per wave spills), the forward transform one stage
   // behind the transform back (+8 %: a fourth stage in the batch's chain), the two halves of the CU's waves a third
   // of a batch out of step (+6 %), a stepped schedule read from a per-wave table (290 spills).
+#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && MF_PRIO_MODE > 0
+  const int wave_young = mvn_uniform((ctx.tid >> 8) & 1);
+#endif
   for (int i = -1; i <= nb; ++i) {
     const cfloat* fin = lds + (i & 1) * MF_BUF;
     cfloat* fout = lds + (2 + (i & 1)) * MF_BUF;
     cfloat* fwd = lds + ((i + 1) & 1) * MF_BUF;
     cfloat* inv = lds + (2 + ((i + 1) & 1)) * MF_BUF;
-    const bool T1 = i >= 1, T2 = i + 1 < nb, F = i >= 0 && i < nb;
+    // MF_ALWAYS_TRANSFORM: the transform stages run in EVERY pass of the loop - in the two passes at either end on lines
+    // nobody wrote (their results go nowhere: mf_store_line_c and mf_fetch test the line's number themselves).  Behind
+    // a test each stage's LDS reads were followed, inside the test's block, by a wait and copies into the registers the
+    // next block expects: the latency the lines of the filter step were dealt out to cover was paid on the spot.
+#if MF_ALWAYS_TRANSFORM
+    constexpr bool T1 = true, T2 = true;
+#else
+    const bool T1 = i >= 1, T2 = i + 1 < nb;
+#endif
+    const bool F = i >= 0 && i < nb;
     const bool fill = i * MF_LINES + MF_LINES - 1 < K - 1;
     const int u = F ? i % (mf_slots(K) / 8) : 0;
+#if defined(MVN_EXPERIMENTS) && defined(MF_STAMPS) && defined(__HIPCC__) && !defined(MVN_HOST_EMU)
+    // timing experiment (probe builds only): shader-clock stamps of every batch, kept in scalar registers; those of one
+    // batch of one workgroup go, per wave, to P.poison_peers' place (a debug buffer of 8 waves x 32 stamps the probe
+    // passes there) at the batch's end.  (A stamp is a scalar memory read: the next wait for LDS data behind it is a wait
+    // for ALL the wave's LDS requests.)
+    unsigned long long mf_stamps[14];
+#define MF_STAMP(n) mf_stamps[n] = __builtin_amdgcn_s_memtime();
+#define MF_STAMP_FLUSH()                                                                                          \
+  if (block == 100 && i == 40 && (ctx.tid & 63) == 0) {                                                           \
+    unsigned long long* dst_ = reinterpret_cast<unsigned long long*>(const_cast<unsigned**>(P.poison_peers)) +    \
+                               (ctx.tid >> 6) * 32;                                                               \
+    for (int n_ = 0; n_ < 14; ++n_) dst_[n_] = mf_stamps[n_];                                                     \
+  }
+#define MF_STAMP_VMWAIT() __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) alone
+#else
+#define MF_STAMP(n)
+#define MF_STAMP_FLUSH()
+#define MF_STAMP_VMWAIT()
+#endif
+#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && MF_PRIO_MODE > 0
+    // (A/B) issue priorities: a SIMD's two waves - w and w + 4 - are served oldest first, so wave w runs ahead, waits
+    // at the batch's barrier, and wave w + 4 finishes alone, at the pace of one wave.  1: the younger wave always ahead;
+    // 2: the two take turns line by line, both raised in the transform stages
+#define MF_PRIO_IF(cond)               \
+  if (cond)                            \
+    __builtin_amdgcn_s_setprio(1);     \
+  else                                 \
+    __builtin_amdgcn_s_setprio(0)
+    // 3: the older wave ahead (the hardware's order) up to point MF_PRIO_SWITCH of the batch, the younger one from there
+#if MF_PRIO_MODE >= 3
+#define MF_LINE_PRIO(C)
+#define MF_STAGE_PRIO()
+#define MF_PRIO_AT(n)                                         \
+  if ((n) == 0)                                               \
+    __builtin_amdgcn_s_setprio(0);                            \
+  else if ((n) == MF_PRIO_SWITCH && wave_young != 0)          \
+    __builtin_amdgcn_s_setprio(2);
+#else
+#define MF_LINE_PRIO(C) MF_PRIO_IF(MF_PRIO_MODE == 1 ? wave_young != 0 : ((((C) ^ wave_young) & 1) != 0))
+#define MF_STAGE_PRIO()                \
+  if (MF_PRIO_MODE == 1) {             \
+    MF_PRIO_IF(wave_young != 0);       \
+  } else                               \
+    __builtin_amdgcn_s_setprio(2)
+#define MF_PRIO_AT(n)
+#endif
+#else
+#define MF_LINE_PRIO(C)
+#define MF_STAGE_PRIO()
+#define MF_PRIO_AT(n)
+#endif
+// (A/B) where in the batch the loads of the batch after the next are issued (the numbers of the MF_STAMP points)
+#define MF_FETCH_AT(n)                                                    \
+  if ((n) == MF_FETCH_POINT) {                                            \
+    MF_WPHASE(ctx, (mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));       \
+  }
 #define MF_FLINE(C)                                                                \
   if (F) {                                                                         \
-    MF_WPHASE(ctx, (mf_fline_dispatch<K, C, 0>(r, fin, fout, u, fill, dc, tid)));  \
+    MF_LINE_PRIO(C);                                                               \
+    MF_WPHASE(ctx, (mf_fread_ahead<K, C>(r, fin, dc, tid), mf_fline_dispatch<K, C, 0>(r, fin, fout, u, fill, dc, tid)));  \
+    MF_STAGE_PRIO();                                                               \
   }
+    MF_STAMP(0)
+    MF_PRIO_AT(0)
+    MF_STAMP_VMWAIT()
+    MF_STAMP(12)
+    // stage A: first stage back (reads the line) | first forward stage (reads the registers loaded ahead)
+#if MF_A_ORDER == 1  // (A/B) the forward stage - whose twiddles it waits for - in front of the batch's other requests
+    if (T2) {
+      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid)));
+      MF_FETCH_AT(1)
+    }
+#endif
     if (F) {
       MF_WPHASE(ctx, (mf_fread<K>(r, fin, 0, dc, tid)));
     }
-    // stage A: first stage back (reads the line) | first forward stage (reads the registers loaded ahead)
     if (T1) {
+      MF_WPHASE(ctx, (mf_inv2_r<K>(r, inv, tid)));
       if (dc) {
-        MF_WPHASE(ctx, (mf_inv2_r_dc<K>(r, inv, tid)));
-      } else {
-        MF_WPHASE(ctx, (mf_inv2_r<K>(r, inv, tid)));
+        MF_WPHASE(ctx, (mf_inv2_fix_dc<K>(r, inv, tid)));
       }
     }
+#if MF_A_ORDER != 1
     if (T2) {
-      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
+      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid)));
+      MF_FETCH_AT(1)
     }
+#endif
+    MF_STAMP(1)
+    MF_PRIO_AT(1)
     MF_FLINE(0)
+    MF_STAMP(2)
+    MF_PRIO_AT(2)
+    MF_FETCH_AT(2)
     if (T1) {
       MF_WPHASE(ctx, (dftR<8, +1>(r.t), mf_inv2_b<K>(r, inv, tid)));
     }
+    MF_STAMP(3)
+    MF_PRIO_AT(3)
+    MF_FETCH_AT(3)
     // stage B
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_r<K>(r, inv, tid)));
@@ -624,14 +773,23 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_r2<K>(r, fwd, tid)));
     }
+    MF_STAMP(4)
+    MF_PRIO_AT(4)
+    MF_FETCH_AT(4)
     MF_FLINE(1)
     MF_FLINE(2)
+    MF_STAMP(5)
+    MF_PRIO_AT(5)
+    MF_FETCH_AT(5)
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid)));
     }
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
     }
+    MF_STAMP(6)
+    MF_PRIO_AT(6)
+    MF_FETCH_AT(6)
     // stage C
     if (T1) {
       MF_WPHASE(ctx, (mf_inv0_r<K>(r, inv, tid)));
@@ -639,19 +797,35 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd2_r2<K>(r, fwd, tid)));
     }
+    MF_STAMP(7)
+    MF_PRIO_AT(7)
+    MF_FETCH_AT(7)
     MF_FLINE(3)
     MF_FLINE(4)
+    MF_STAMP(8)
+    MF_PRIO_AT(8)
+    MF_FETCH_AT(8)
     if (T1) {
       MF_WPHASE(ctx, (mf_store_line_c<K>(P, r, twl, c, z0, nout, i - 1, tid)));
     }
     if (T2) {
       MF_WPHASE(ctx, (dftR<8, -1>(r.t2), mf_fwd2_b2<K>(r, fwd, tid)));
     }
+    MF_STAMP(9)
+    MF_PRIO_AT(9)
+    MF_FETCH_AT(9)
     MF_FLINE(5)
     MF_FLINE(6)
     MF_FLINE(7)
+    MF_STAMP(10)
+    MF_PRIO_AT(10)
+    MF_FETCH_AT(10)
 #undef MF_FLINE
     MVN_PHASE(ctx, (void)0);
+    MF_STAMP(11)
+    MF_PRIO_AT(11)
+    MF_FETCH_AT(11)
+    MF_STAMP_FLUSH()
   }
   MVN_PHASE_NOSYNC(ctx, (mf_report<K>(P, r)));
 }

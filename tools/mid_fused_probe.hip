@@ -70,6 +70,12 @@ static void run(MidFusedParams P, int launches, const std::vector<cfloat>& h_in,
   P.tw = d_tw;
   P.poison = d_poison;
   P.poison_epoch = 7;
+#ifdef MF_STAMPS
+  unsigned long long* d_stamps;
+  CK(hipMalloc(&d_stamps, 8 * 32 * sizeof(unsigned long long)));
+  CK(hipMemset(d_stamps, 0, 8 * 32 * sizeof(unsigned long long)));
+  P.poison_peers = reinterpret_cast<unsigned* const*>(d_stamps);  // (n_peers stays 0: never read as peers)
+#endif
   const size_t lds = MF_LDS_CFLOATS * sizeof(cfloat);
   CK(hipFuncSetAttribute((const void*)kf_mid<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipFuncAttributes fa;
@@ -99,6 +105,29 @@ static void run(MidFusedParams P, int launches, const std::vector<cfloat>& h_in,
   unsigned pw = 0;
   CK(hipMemcpy(&pw, d_poison, 4, hipMemcpyDeviceToHost));
   printf("poison word %u\n", pw);
+#ifdef MF_STAMPS
+  {
+    unsigned long long st[8][32];
+    CK(hipMemcpy(st, d_stamps, sizeof(st), hipMemcpyDeviceToHost));
+    static const char* names[12] = {"batch start", "A requests (inv2 reads, fwd0 + stores, loads)", "filter line 0", "A inv2 arithmetic + writes",
+                                    "B requests", "filter lines 1 2", "B arithmetic + writes", "C requests", "filter lines 3 4",
+                                    "C arithmetic + stores / writes", "filter lines 5 6 7", "barrier"};
+    printf("shader-clock ticks per step of batch 40 of workgroup 100 (per wave; the step ends at the stamp):\n");
+    printf("  %-48s", "wait for the last batch's loads and stores");
+    for (int w = 0; w < 8; ++w) printf(" %6lld", (long long)(st[w][12] - st[w][0]));
+    printf("\n");
+    for (int n = 1; n < 12; ++n) {
+      printf("  %-48s", names[n]);
+      for (int w = 0; w < 8; ++w) printf(" %6lld", (long long)(st[w][n] - st[w][n == 1 ? 12 : n - 1]));
+      printf("\n");
+    }
+    printf("  %-48s", "whole batch");
+    for (int w = 0; w < 8; ++w) printf(" %6lld", (long long)(st[w][11] - st[w][0]));
+    printf("\n  start of the batch relative to wave 0:              ");
+    for (int w = 0; w < 8; ++w) printf(" %6lld", (long long)(st[w][0] - st[0][0]));
+    printf("\n");
+  }
+#endif
 #else
   P.in = h_in.data();
   P.out = h_out.data();

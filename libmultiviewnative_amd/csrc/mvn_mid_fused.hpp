@@ -698,11 +698,23 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
 #if MF_PRIO_MODE >= 3
 #define MF_LINE_PRIO(C)
 #define MF_STAGE_PRIO()
+#if MF_PRIO_MODE == 4  // (A/B) as 3, and every wave raised above both levels while it is in a transform stage
+#define MF_PRIO_AT(n)                                                         \
+  if ((n) == 0 || (n) == 2 || (n) == 5 || (n) == 8)                           \
+    __builtin_amdgcn_s_setprio(3);                                            \
+  else if ((n) == 1 || (n) == 4 || (n) == 7 || (n) == 9) {                    \
+    if ((n) >= MF_PRIO_SWITCH && wave_young != 0)                             \
+      __builtin_amdgcn_s_setprio(2);                                          \
+    else                                                                      \
+      __builtin_amdgcn_s_setprio(0);                                          \
+  }
+#else
 #define MF_PRIO_AT(n)                                         \
   if ((n) == 0)                                               \
     __builtin_amdgcn_s_setprio(0);                            \
   else if ((n) == MF_PRIO_SWITCH && wave_young != 0)          \
     __builtin_amdgcn_s_setprio(2);
+#endif
 #else
 #define MF_LINE_PRIO(C) MF_PRIO_IF(MF_PRIO_MODE == 1 ? wave_young != 0 : ((((C) ^ wave_young) & 1) != 0))
 #define MF_STAGE_PRIO()                \

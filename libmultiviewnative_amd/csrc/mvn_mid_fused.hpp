@@ -101,6 +101,9 @@ enum { MF_DC_NONE = 0, MF_DC_LOW = 1, MF_DC_HIGH = 2, MF_DC_SELF = 3 };  // a wo
 
 constexpr int mf_slots(int K) { return (K + 7) / 8 * 8; }
 
+#ifndef MF_TW0_AHEAD  // (see mf_tw0_ahead)
+#define MF_TW0_AHEAD 1
+#endif
 template <int K>
 struct MfRegs {
   cfloat tap[K];
@@ -233,10 +236,27 @@ MVN_HD void mf_fwd0(MfRegs<K>& r, cfloat* buf, const cfloat* twl, int tid) {
 #pragma unroll
   for (int m = 0; m < 8; ++m) a[m] = r.xr[m];
   dftR<8, -1>(a);
+#if MF_TW0_AHEAD
+  (void)twl;
+#pragma unroll
+  for (int m = 1; m < 8; ++m) a[m] = mf_cmul(a[m], r.t2[m]);
+#else
 #pragma unroll
   for (int m = 1; m < 8; ++m) a[m] = mf_cmul(a[m], mf_tw0(twl, l, m));
+#endif
 #pragma unroll
   for (int m = 0; m < 8; ++m) line[72 * m + l] = a[m];  // sub-line m (frequencies m + 8 .), element l
+}
+// MF_TW0_AHEAD: the first forward stage is the first thing a wave does behind the batch's barrier, and it waited there
+// for its seven twiddles behind every other wave's LDS requests.  They are requested in front of the barrier instead,
+// into r.t2 - which holds nothing between the last forward stage of a batch and the second one of the next.
+template <int K>
+MVN_HD void mf_tw0_ahead(MfRegs<K>& r, const cfloat* twl, int tid) {
+#if MF_TW0_AHEAD
+  const int l = tid & 63;
+#pragma unroll
+  for (int m = 1; m < 8; ++m) r.t2[m] = mf_tw0(twl, l, m);
+#endif
 }
 // Every exchange stage is a pair: `_a` reads the lane's inputs from the line and computes into r.t, `_b` writes
 // r.t to the places the NEXT stage reads.  On the device the two run back to back (a wave's LDS instructions
@@ -374,6 +394,21 @@ MVN_HD void mf_inv1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
   for (int m = 1; m < 8; ++m) r.t[m] = mf_cmulc(r.t[m], mf_tw1(twl, l, m));
   dftR<8, +1>(r.t);
 }
+// stage B's arithmetic of a wave's two lines in one: the forward stage (r.t2: transform, then twiddles) and the stage
+// back (r.t: conjugate twiddles, then transform) multiply by the SAME seven table entries - one LDS read each instead of two
+template <int K>
+MVN_HD void mf_pair1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
+  const int l = tid & 63;
+  (void)l;
+  dftR<8, -1>(r.t2);
+#pragma unroll
+  for (int m = 1; m < 8; ++m) {
+    const cfloat tw = mf_tw1(twl, l, m);
+    r.t[m] = mf_cmulc(r.t[m], tw);
+    r.t2[m] = mf_cmul(r.t2[m], tw);
+  }
+  dftR<8, +1>(r.t);
+}
 template <int K>
 MVN_HD void mf_inv1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
   mf_inv1_r<K>(r, buf, tid);
@@ -492,6 +527,10 @@ MVN_HD void mf_setup_dc(const MidFusedParams& P, MfRegs<K>& r, int tid) {
 #ifndef MF_A_ORDER
 #define MF_A_ORDER 0
 #endif
+#ifndef MF_PAIR_TW1  // (A/B, see mf_pair1_c: 7 LDS reads fewer per wave and batch, +2 % at K = 31 - the two lines' stages in one block wait together)
+#define MF_PAIR_TW1 0
+#endif
+
 // Issue priorities within a batch (device only).  A SIMD's two waves - w and w + 4 of the workgroup - are served oldest
 // first: wave w runs ahead (good: its transform stages wait for the LDS while wave w + 4 still multiplies), reaches the
 // batch's barrier ~3000 cycles early, and wave w + 4 finishes alone at the pace of one wave (shader-clock stamps,
@@ -637,6 +676,7 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     MVN_PHASE_NOSYNC(ctx, (mf_setup_dc<K>(P, r, tid)));
   }
   MVN_PHASE(ctx, (void)0);
+  MVN_PHASE_NOSYNC(ctx, (mf_tw0_ahead<K>(r, twl, tid)));
   // Four line buffers: the forward transforms of batch i + 1 go to FW[(i + 1) & 1], the filter step of batch i reads
   // FW[i & 1] and writes OU[i & 1], the transforms back of batch i - 1 read OU[(i - 1) & 1].  A wave's forward and
   // backward transform of an iteration are then independent of each other (two lines, two register sets): their
@@ -793,12 +833,16 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     MF_STAMP(5)
     MF_PRIO_AT(5)
     MF_FETCH_AT(5)
+#if MF_ALWAYS_TRANSFORM && MF_PAIR_TW1
+    MF_WPHASE(ctx, (mf_pair1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid), mf_fwd1_b2<K>(r, fwd, tid)));
+#else
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid)));
     }
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
     }
+#endif
     MF_STAMP(6)
     MF_PRIO_AT(6)
     MF_FETCH_AT(6)
@@ -833,6 +877,7 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     MF_PRIO_AT(10)
     MF_FETCH_AT(10)
 #undef MF_FLINE
+    MF_WPHASE(ctx, (mf_tw0_ahead<K>(r, twl, tid)));
     MVN_PHASE(ctx, (void)0);
     MF_STAMP(11)
     MF_PRIO_AT(11)
@@ -867,6 +912,7 @@ MVN_HD void mf_taps_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& 
   const int c = (int)(block - batch * P.H);
   cfloat* twl = lds + 4 * MF_BUF;
   MVN_PHASE(ctx, (mf_taps_load(P, r, batch, c, tid), mf_build_twiddles(P, twl, tid)));
+  MF_WPHASE(ctx, (mf_tw0_ahead<1>(r, twl, tid)));
   MF_WPHASE(ctx, (mf_fwd0<1>(r, lds, twl, tid)));
   MF_WPHASE(ctx, (mf_fwd1_a<1>(r, lds, twl, tid)));
   MF_WPHASE(ctx, (mf_fwd1_b<1>(r, lds, tid)));

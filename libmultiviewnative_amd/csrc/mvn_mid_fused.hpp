@@ -227,6 +227,30 @@ MVN_HD void mf_build_twiddles(const MidFusedParams& P, cfloat* twl, int tid) {
 MVN_HD cfloat mf_tw0(const cfloat* twl, int l, int m) { return twl[(m - 1) * 64 + l]; }
 MVN_HD cfloat mf_tw1(const cfloat* twl, int l, int m) { return twl[448 + (m - 1) * 8 + (l & 7)]; }
 
+// the transforms' 8-point butterflies (one place for two timing experiments, probe builds only, WRONG results:
+// MF_EXP_NO_DFT leaves them out - what do they cost? -, MF_EXP_MFMA_DUMMY issues beside each the sixteen
+// v_mfma_f32_16x16x4_f32 a 16 x 16 real matrix form of it would take - does the matrix pipe run beside the rest?)
+template <int SIGN>
+MVN_HD void mf_dft8(cfloat* a, cfloat& sink) {
+  (void)sink;
+#if !(defined(MVN_EXPERIMENTS) && defined(MF_EXP_NO_DFT))
+  dftR<8, SIGN>(a);
+#endif
+#if defined(MVN_EXPERIMENTS) && defined(MF_EXP_MFMA_DUMMY) && defined(__HIPCC__) && !defined(MVN_HOST_EMU)
+  typedef float mf_f4 __attribute__((ext_vector_type(4)));
+  mf_f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+  const float x = sink.x, y = sink.y;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, x, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, y, c3, 0, 0, 0);
+  }
+  sink.x += (c0.x + c1.y) + (c2.z + c3.w);
+#endif
+}
+
 // ---- forward transform of a wave's line: registers -> LDS line, bins in the order q = 64 j + 8 k + a ----
 template <int K>
 MVN_HD void mf_fwd0(MfRegs<K>& r, cfloat* buf, const cfloat* twl, int tid) {
@@ -235,7 +259,7 @@ MVN_HD void mf_fwd0(MfRegs<K>& r, cfloat* buf, const cfloat* twl, int tid) {
   cfloat a[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) a[m] = r.xr[m];
-  dftR<8, -1>(a);
+  mf_dft8<-1>(a, r.bad);
 #if MF_TW0_AHEAD
   (void)twl;
 #pragma unroll
@@ -273,7 +297,7 @@ template <int K>
 MVN_HD void mf_fwd1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
   const int l = tid & 63;
   (void)l;
-  dftR<8, -1>(r.t);
+  mf_dft8<-1>(r.t, r.bad);
 #pragma unroll
   for (int m = 1; m < 8; ++m) r.t[m] = mf_cmul(r.t[m], mf_tw1(twl, l, m));
 }
@@ -290,7 +314,7 @@ template <int K>
 MVN_HD void mf_fwd1_c2(MfRegs<K>& r, const cfloat* twl, int tid) {
   const int l = tid & 63;
   (void)l;
-  dftR<8, -1>(r.t2);
+  mf_dft8<-1>(r.t2, r.bad);
 #pragma unroll
   for (int m = 1; m < 8; ++m) r.t2[m] = mf_cmul(r.t2[m], mf_tw1(twl, l, m));
 }
@@ -343,7 +367,7 @@ MVN_HD void mf_fwd2_r(MfRegs<K>& r, const cfloat* buf, int tid) {
 template <int K>
 MVN_HD void mf_fwd2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
   mf_fwd2_r<K>(r, buf, tid);
-  dftR<8, -1>(r.t);
+  mf_dft8<-1>(r.t, r.bad);
 }
 template <int K>
 MVN_HD void mf_fwd2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
@@ -364,7 +388,7 @@ MVN_HD void mf_inv2_r(MfRegs<K>& r, const cfloat* buf, int tid) {
 template <int K>
 MVN_HD void mf_inv2_a(MfRegs<K>& r, const cfloat* buf, int tid) {
   mf_inv2_r<K>(r, buf, tid);
-  dftR<8, +1>(r.t);
+  mf_dft8<+1>(r.t, r.bad);
 }
 template <int K>
 MVN_HD void mf_inv2_b(const MfRegs<K>& r, cfloat* buf, int tid) {
@@ -392,7 +416,7 @@ MVN_HD void mf_inv1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
   (void)l;
 #pragma unroll
   for (int m = 1; m < 8; ++m) r.t[m] = mf_cmulc(r.t[m], mf_tw1(twl, l, m));
-  dftR<8, +1>(r.t);
+  mf_dft8<+1>(r.t, r.bad);
 }
 // stage B's arithmetic of a wave's two lines in one: the forward stage (r.t2: transform, then twiddles) and the stage
 // back (r.t: conjugate twiddles, then transform) multiply by the SAME seven table entries - one LDS read each instead of two
@@ -400,14 +424,14 @@ template <int K>
 MVN_HD void mf_pair1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
   const int l = tid & 63;
   (void)l;
-  dftR<8, -1>(r.t2);
+  mf_dft8<-1>(r.t2, r.bad);
 #pragma unroll
   for (int m = 1; m < 8; ++m) {
     const cfloat tw = mf_tw1(twl, l, m);
     r.t[m] = mf_cmulc(r.t[m], tw);
     r.t2[m] = mf_cmul(r.t2[m], tw);
   }
-  dftR<8, +1>(r.t);
+  mf_dft8<+1>(r.t, r.bad);
 }
 template <int K>
 MVN_HD void mf_inv1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
@@ -433,7 +457,7 @@ MVN_HD void mf_inv0_c_store(MfRegs<K>& r, const cfloat* twl, cfloat* dst, int ti
   const int l = tid & 63;
 #pragma unroll
   for (int m = 1; m < 8; ++m) r.t[m] = mf_cmulc(r.t[m], mf_tw0(twl, l, m));
-  dftR<8, +1>(r.t);
+  mf_dft8<+1>(r.t, r.bad);
 #if defined(MVN_EXPERIMENTS) && defined(MF_EXP_NOSTORE)  // timing experiment (probe builds only, WRONG results): what the stores cost
   if (r.t[0].x == 12345.678f)
 #endif
@@ -813,7 +837,7 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     MF_PRIO_AT(2)
     MF_FETCH_AT(2)
     if (T1) {
-      MF_WPHASE(ctx, (dftR<8, +1>(r.t), mf_inv2_b<K>(r, inv, tid)));
+      MF_WPHASE(ctx, (mf_dft8<+1>(r.t, r.bad), mf_inv2_b<K>(r, inv, tid)));
     }
     MF_STAMP(3)
     MF_PRIO_AT(3)
@@ -865,7 +889,7 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
       MF_WPHASE(ctx, (mf_store_line_c<K>(P, r, twl, c, z0, nout, i - 1, tid)));
     }
     if (T2) {
-      MF_WPHASE(ctx, (dftR<8, -1>(r.t2), mf_fwd2_b2<K>(r, fwd, tid)));
+      MF_WPHASE(ctx, (mf_dft8<-1>(r.t2, r.bad), mf_fwd2_b2<K>(r, fwd, tid)));
     }
     MF_STAMP(9)
     MF_PRIO_AT(9)

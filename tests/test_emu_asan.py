@@ -32,7 +32,7 @@ def test_fixed_and_wave_row_kernels_under_asan():
     # line-layout last-axis passes (its LDS line buffers are a host vector here); -p no:cacheprovider: the child must not fight the parent over .pytest_cache
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_emu_engine.py"), "-q", "-x",
                         "-p", "no:cacheprovider", "-k", "mixed_radix or wave_row or long_rows or fixed or direct_dim0 or fused_middle_pass_in_the_simultaneous "
-                              "or default_padding_policy_reaches or slabs_run_the_fused"],
+                              "or default_padding_policy_reaches or (slabs_run_the_fused and not None)"],  # (one of the two slab cases: 50 s each here)
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     tail = r.stdout[-3000:] + r.stderr[-3000:]
     assert r.returncode == 0, tail

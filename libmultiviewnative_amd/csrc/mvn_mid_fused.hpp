@@ -418,21 +418,6 @@ MVN_HD void mf_inv1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
   for (int m = 1; m < 8; ++m) r.t[m] = mf_cmulc(r.t[m], mf_tw1(twl, l, m));
   mf_dft8<+1>(r.t, r.bad);
 }
-// stage B's arithmetic of a wave's two lines in one: the forward stage (r.t2: transform, then twiddles) and the stage
-// back (r.t: conjugate twiddles, then transform) multiply by the SAME seven table entries - one LDS read each instead of two
-template <int K>
-MVN_HD void mf_pair1_c(MfRegs<K>& r, const cfloat* twl, int tid) {
-  const int l = tid & 63;
-  (void)l;
-  mf_dft8<-1>(r.t2, r.bad);
-#pragma unroll
-  for (int m = 1; m < 8; ++m) {
-    const cfloat tw = mf_tw1(twl, l, m);
-    r.t[m] = mf_cmulc(r.t[m], tw);
-    r.t2[m] = mf_cmul(r.t2[m], tw);
-  }
-  mf_dft8<+1>(r.t, r.bad);
-}
 template <int K>
 MVN_HD void mf_inv1_a(MfRegs<K>& r, const cfloat* buf, const cfloat* twl, int tid) {
   mf_inv1_r<K>(r, buf, tid);
@@ -538,32 +523,23 @@ MVN_HD void mf_setup_dc(const MidFusedParams& P, MfRegs<K>& r, int tid) {
 // U = (batch mod KW / 8): step n = 8 batch + C fills slot 8 U + C; tap j multiplies the input of step n - j.
 // FILL: the first K - 1 steps of a walk only fill the window.  The input of a line is requested one line ahead
 // (r.xn, in the DC column r.xp as well).
-// MF_READ_AHEAD: the request for line C + 1 in front of line C, in code every variant of the line shares.  Issued
-// inside the variants (behind line C's last multiply-add), each variant's read was a different instruction, the value
-// a merge of them: the compiler read into a scratch register and waited for it at the end of every variant - a whole
-// LDS latency per line, 8 per batch (ISA of the round's first build; 0 restores that form for the comparison).
-#ifndef MF_READ_AHEAD
-#define MF_READ_AHEAD 1
-#endif
+// The request for line C + 1 is issued in front of line C, in code every variant of the line shares (mf_fread_ahead),
+// into one of two alternating registers.  Issued inside the variants (behind line C's last multiply-add), each
+// variant's read was a different instruction and the value a merge of them: the compiler read into a scratch register
+// and waited for it at the end of every variant - a whole LDS latency per line, 8 per batch.
+//
+// MF_ALWAYS_TRANSFORM (0: the form before, kept for same-box comparisons): see mf_body.
 #ifndef MF_ALWAYS_TRANSFORM
 #define MF_ALWAYS_TRANSFORM 1
 #endif
-#ifndef MF_A_ORDER
-#define MF_A_ORDER 0
-#endif
-#ifndef MF_PAIR_TW1  // (A/B, see mf_pair1_c: 7 LDS reads fewer per wave and batch, +2 % at K = 31 - the two lines' stages in one block wait together)
-#define MF_PAIR_TW1 0
-#endif
-
 // Issue priorities within a batch (device only).  A SIMD's two waves - w and w + 4 of the workgroup - are served oldest
 // first: wave w runs ahead (good: its transform stages wait for the LDS while wave w + 4 still multiplies), reaches the
 // batch's barrier ~3000 cycles early, and wave w + 4 finishes alone at the pace of one wave (shader-clock stamps,
-// profiles/r04_mid_fused.md).  Mode 3 keeps the hardware's order up to point MF_PRIO_SWITCH of the batch (the numbers
-// of the MF_STAMP points) and raises the younger wave from there: both reach the barrier together.  0: none;
-// 1, 2: earlier experiments (the younger wave always ahead; turns line by line) - no gain.
-#ifndef MF_FETCH_POINT
-#define MF_FETCH_POINT 1
-#endif
+// profiles/r04_mid_fused.md).  MF_PRIO_MODE 3 keeps the hardware's order up to point MF_PRIO_SWITCH of the batch (the
+// numbers of the MF_STAMP points) and raises the younger wave from there: both reach the barrier together.  0: none.
+// (Measured and removed: the younger wave always ahead, turns line by line, every wave raised inside its transform
+// stages; the forward stage in front of the batch's other requests; the loads issued later in the batch; stage B's
+// arithmetic of both lines as one block on shared twiddles - profiles/r04_mid_fused.md.)
 #ifndef MF_PRIO_MODE
 #define MF_PRIO_MODE 3
 #endif
@@ -590,9 +566,6 @@ MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc,
   constexpr int KW = mf_slots(K), S = 8 * U + C;
   if (FILL) {
     r.w[S] = mf_filter_input<K>(r, C, dc);
-#if !MF_READ_AHEAD
-    if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
-#endif
     return;
   }
   // OLDEST taps first: they multiply values that have sat in the registers for up to K steps.  The line's own input
@@ -625,9 +598,6 @@ MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc,
     s2 = cadd(s2, a2[ch]);
   }
   r.w[S] = x;
-#if !MF_READ_AHEAD
-  if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
-#endif
   r.bad = mvn_dim0_track(r.bad, x);
   cfloat o = cadd_i<+1>(s1, s2);
   if (dc) o = r.dcmode == MF_DC_SELF ? cmake(s1.x, s2.y) : o;
@@ -635,9 +605,7 @@ MVN_HD void mf_filter_line(MfRegs<K>& r, const cfloat* in, cfloat* out, bool dc,
 }
 template <int K, int C>
 MVN_HD void mf_fread_ahead(MfRegs<K>& r, const cfloat* in, bool dc, int tid) {
-#if MF_READ_AHEAD
   if (C + 1 < MF_LINES) mf_fread<K>(r, in, C + 1, dc, tid);
-#endif
 }
 template <int K, int C, int U>
 MVN_HD void mf_fline_dispatch(MfRegs<K>& r, const cfloat* in, cfloat* out, int u, bool fill, bool dc, int tid) {
@@ -710,7 +678,7 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
   // transforms (+3 .. +18 %, and the loop that selects the order per wave spills), the forward transform one stage
   // behind the transform back (+8 %: a fourth stage in the batch's chain), the two halves of the CU's waves a third
   // of a batch out of step (+6 %), a stepped schedule read from a per-wave table (290 spills).
-#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && MF_PRIO_MODE > 0
+#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && MF_PRIO_MODE == 3
   const int wave_young = mvn_uniform((ctx.tid >> 8) & 1);
 #endif
   for (int i = -1; i <= nb; ++i) {
@@ -749,72 +717,24 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
 #define MF_STAMP_FLUSH()
 #define MF_STAMP_VMWAIT()
 #endif
-#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && MF_PRIO_MODE > 0
-    // (A/B) issue priorities: a SIMD's two waves - w and w + 4 - are served oldest first, so wave w runs ahead, waits
-    // at the batch's barrier, and wave w + 4 finishes alone, at the pace of one wave.  1: the younger wave always ahead;
-    // 2: the two take turns line by line, both raised in the transform stages
-#define MF_PRIO_IF(cond)               \
-  if (cond)                            \
-    __builtin_amdgcn_s_setprio(1);     \
-  else                                 \
-    __builtin_amdgcn_s_setprio(0)
-    // 3: the older wave ahead (the hardware's order) up to point MF_PRIO_SWITCH of the batch, the younger one from there
-#if MF_PRIO_MODE >= 3
-#define MF_LINE_PRIO(C)
-#define MF_STAGE_PRIO()
-#if MF_PRIO_MODE == 4  // (A/B) as 3, and every wave raised above both levels while it is in a transform stage
-#define MF_PRIO_AT(n)                                                         \
-  if ((n) == 0 || (n) == 2 || (n) == 5 || (n) == 8)                           \
-    __builtin_amdgcn_s_setprio(3);                                            \
-  else if ((n) == 1 || (n) == 4 || (n) == 7 || (n) == 9) {                    \
-    if ((n) >= MF_PRIO_SWITCH && wave_young != 0)                             \
-      __builtin_amdgcn_s_setprio(2);                                          \
-    else                                                                      \
-      __builtin_amdgcn_s_setprio(0);                                          \
-  }
-#else
+#if defined(__HIPCC__) && !defined(MVN_HOST_EMU) && MF_PRIO_MODE == 3
 #define MF_PRIO_AT(n)                                         \
   if ((n) == 0)                                               \
     __builtin_amdgcn_s_setprio(0);                            \
   else if ((n) == MF_PRIO_SWITCH && wave_young != 0)          \
     __builtin_amdgcn_s_setprio(2);
-#endif
 #else
-#define MF_LINE_PRIO(C) MF_PRIO_IF(MF_PRIO_MODE == 1 ? wave_young != 0 : ((((C) ^ wave_young) & 1) != 0))
-#define MF_STAGE_PRIO()                \
-  if (MF_PRIO_MODE == 1) {             \
-    MF_PRIO_IF(wave_young != 0);       \
-  } else                               \
-    __builtin_amdgcn_s_setprio(2)
 #define MF_PRIO_AT(n)
 #endif
-#else
-#define MF_LINE_PRIO(C)
-#define MF_STAGE_PRIO()
-#define MF_PRIO_AT(n)
-#endif
-// (A/B) where in the batch the loads of the batch after the next are issued (the numbers of the MF_STAMP points)
-#define MF_FETCH_AT(n)                                                    \
-  if ((n) == MF_FETCH_POINT) {                                            \
-    MF_WPHASE(ctx, (mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));       \
-  }
 #define MF_FLINE(C)                                                                \
   if (F) {                                                                         \
-    MF_LINE_PRIO(C);                                                               \
     MF_WPHASE(ctx, (mf_fread_ahead<K, C>(r, fin, dc, tid), mf_fline_dispatch<K, C, 0>(r, fin, fout, u, fill, dc, tid)));  \
-    MF_STAGE_PRIO();                                                               \
   }
     MF_STAMP(0)
     MF_PRIO_AT(0)
     MF_STAMP_VMWAIT()
     MF_STAMP(12)
     // stage A: first stage back (reads the line) | first forward stage (reads the registers loaded ahead)
-#if MF_A_ORDER == 1  // (A/B) the forward stage - whose twiddles it waits for - in front of the batch's other requests
-    if (T2) {
-      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid)));
-      MF_FETCH_AT(1)
-    }
-#endif
     if (F) {
       MF_WPHASE(ctx, (mf_fread<K>(r, fin, 0, dc, tid)));
     }
@@ -824,24 +744,19 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
         MF_WPHASE(ctx, (mf_inv2_fix_dc<K>(r, inv, tid)));
       }
     }
-#if MF_A_ORDER != 1
     if (T2) {
-      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid)));
-      MF_FETCH_AT(1)
+      MF_WPHASE(ctx, (mf_fwd0<K>(r, fwd, twl, tid), mf_fetch<K>(P, r, c, z0, i + 2, nsteps, tid)));
     }
-#endif
     MF_STAMP(1)
     MF_PRIO_AT(1)
     MF_FLINE(0)
     MF_STAMP(2)
     MF_PRIO_AT(2)
-    MF_FETCH_AT(2)
     if (T1) {
       MF_WPHASE(ctx, (mf_dft8<+1>(r.t, r.bad), mf_inv2_b<K>(r, inv, tid)));
     }
     MF_STAMP(3)
     MF_PRIO_AT(3)
-    MF_FETCH_AT(3)
     // stage B
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_r<K>(r, inv, tid)));
@@ -851,25 +766,18 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     }
     MF_STAMP(4)
     MF_PRIO_AT(4)
-    MF_FETCH_AT(4)
     MF_FLINE(1)
     MF_FLINE(2)
     MF_STAMP(5)
     MF_PRIO_AT(5)
-    MF_FETCH_AT(5)
-#if MF_ALWAYS_TRANSFORM && MF_PAIR_TW1
-    MF_WPHASE(ctx, (mf_pair1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid), mf_fwd1_b2<K>(r, fwd, tid)));
-#else
     if (T1) {
       MF_WPHASE(ctx, (mf_inv1_c<K>(r, twl, tid), mf_inv1_b<K>(r, inv, tid)));
     }
     if (T2) {
       MF_WPHASE(ctx, (mf_fwd1_c2<K>(r, twl, tid), mf_fwd1_b2<K>(r, fwd, tid)));
     }
-#endif
     MF_STAMP(6)
     MF_PRIO_AT(6)
-    MF_FETCH_AT(6)
     // stage C
     if (T1) {
       MF_WPHASE(ctx, (mf_inv0_r<K>(r, inv, tid)));
@@ -879,12 +787,10 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     }
     MF_STAMP(7)
     MF_PRIO_AT(7)
-    MF_FETCH_AT(7)
     MF_FLINE(3)
     MF_FLINE(4)
     MF_STAMP(8)
     MF_PRIO_AT(8)
-    MF_FETCH_AT(8)
     if (T1) {
       MF_WPHASE(ctx, (mf_store_line_c<K>(P, r, twl, c, z0, nout, i - 1, tid)));
     }
@@ -893,19 +799,16 @@ MVN_HD void mf_body(const MidFusedParams& P, long block, cfloat* lds, Ctx& ctx) 
     }
     MF_STAMP(9)
     MF_PRIO_AT(9)
-    MF_FETCH_AT(9)
     MF_FLINE(5)
     MF_FLINE(6)
     MF_FLINE(7)
     MF_STAMP(10)
     MF_PRIO_AT(10)
-    MF_FETCH_AT(10)
 #undef MF_FLINE
     MF_WPHASE(ctx, (mf_tw0_ahead<K>(r, twl, tid)));
     MVN_PHASE(ctx, (void)0);
     MF_STAMP(11)
     MF_PRIO_AT(11)
-    MF_FETCH_AT(11)
     MF_STAMP_FLUSH()
   }
   MVN_PHASE_NOSYNC(ctx, (mf_report<K>(P, r)));

@@ -1631,6 +1631,23 @@ def test_fused_middle_pass_on_the_line_layout_vs_oracle(gpu, orc, monkeypatch, s
     gpu.check(gpu.l.mvn_release_cached_engines())
 
 
+@pytest.mark.parametrize("k0,d0", [(1, 12), (5, 29), (11, 24), (13, 40), (21, 33), (27, 38), (29, 39)])
+def test_fused_middle_pass_other_tap_counts_vs_oracle(gpu, orc, monkeypatch, k0, d0):
+    # the tap-count templates of kf_mid<K> the cases above do not reach (tools/fuzz_mid_fused.py walks all 31 depths)
+    monkeypatch.setenv("MVN_PAD_MODE", "none")
+    monkeypatch.setenv("MVN_MID_FUSED", "2")
+    gpu.check(gpu.l.mvn_release_cached_engines())
+    shape, kshape = (d0, 512, 512), (k0, 3, 3)
+    _, views, k1, k2, w, psi0 = realistic_views(shape, 2, kshape, seed=100 + k0)
+    h = WorkspaceHolder(views, k1, k2, w, 0.006, 1e-4, 2)
+    c0 = gpu.l.mvn_mid_fused_launch_count()
+    got = gpu.gpu_deconvolve(psi0, h)
+    assert gpu.l.mvn_mid_fused_launch_count() - c0 == 2 * 2 * 2  # iterations x views x convolutions
+    mx, rms = rel_err(got, orc.cpu_deconvolve(psi0, h, -1))
+    assert mx <= 1e-5 and rms <= 1e-6, (k0, d0, mx, rms)
+    gpu.check(gpu.l.mvn_release_cached_engines())
+
+
 def test_fused_middle_pass_nonfinite_voxel_and_fallbacks(gpu, orc, monkeypatch):
     # one Inf voxel (in psi, in a view) floods the volume through the fused middle pass as it does through an FFT
     # along dim0 (inc/cpu_convolve.h:256-268 + inc/cpu_kernels.h:40-47,76-83); the simultaneous step of the same
